@@ -1,0 +1,48 @@
+// TEST INFRASTRUCTURE ONLY -- C entry points of the CPU oracle for ctypes.
+// Loaded by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the
+// product library never links or loads this file.
+#include "rt_oracle.hpp"
+
+using namespace rto;
+
+extern "C" {
+
+// policy: 0 = RefPolicy (double, libm), 1 = DevPolicy (float, portable math).
+// rng_mode: 0 = per-thread streams (the reference's order), 1 = per-pixel streams.
+// Returns 0, -1 if a loop guard tripped (scene outside the reference's defined
+// behaviour), -2 on bad arguments.
+int oracle_render(const double* params, int n_prims, const double* prims, int n_mats, const double* mats,
+                  int n_verts, const double* verts, int policy, int rng_mode, int n_workers,
+                  int row_begin, int row_end, double* rgb, int64_t* rays, int32_t* hit_ids, int32_t* pix_rays) {
+    if (!params || !prims || !mats || !rgb || !rays) return -2;
+    SceneD sc;
+    sc.n_prims = n_prims; sc.prims = prims; sc.n_mats = n_mats; sc.mats = mats; sc.n_verts = n_verts; sc.verts = verts;
+    if (policy == 0) return render<RefPolicy>(sc, params, rng_mode, n_workers, row_begin, row_end, rgb, rays, hit_ids, pix_rays);
+    if (policy == 1) return render<DevPolicy>(sc, params, rng_mode, n_workers, row_begin, row_end, rgb, rays, hit_ids, pix_rays);
+    return -2;
+}
+
+void oracle_expose(int width, int height, double exposure, int num_blurs, int n_workers, double* rgb, int32_t* img) {
+    expose(width, height, exposure, num_blurs, n_workers, rgb, img);
+}
+
+uint32_t oracle_pixel_seed(uint32_t pixel_index, uint32_t frame_seed) { return pixel_seed(pixel_index, frame_seed); }
+
+void oracle_rng_stream(uint32_t state, int n, uint32_t* out) {
+    Rng g; g.s = state;
+    for (int i = 0; i < n; i++) out[i] = g.next();
+}
+
+// fn: 0 sin, 1 cos, 2 acos, 3 pow(x,y)
+void oracle_math(int fn, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: out[i] = orm::p_sin(x[i]); break;
+            case 1: out[i] = orm::p_cos(x[i]); break;
+            case 2: out[i] = orm::p_acos(x[i]); break;
+            default: out[i] = orm::p_pow(x[i], y[i]); break;
+        }
+    }
+}
+
+}  // extern "C"
