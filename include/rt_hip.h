@@ -1,0 +1,174 @@
+/* rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) implementation of the
+ * per-pixel render loop of samkottler/rayTracer.
+ *
+ * The reference has no plugin or FFI interface; its render loop is the function
+ * do_rays_i(Color* img, int num) that main() runs on num_threads std::threads
+ * (/root/reference/src/main.cpp:247-289, spawned at :304-313), reading the scene
+ * from globals that read_json_scene() filled (/root/reference/src/readShape.cpp:
+ * 13-24,31-42) and writing Color colors[width*height] plus long num_rays[T].
+ * This library replaces exactly that seam: the host loads a scene, hands it over
+ * once as flat tables, and one rt_render* call fills the radiance array and the
+ * ray counter.  Everything else of main() (expose/blur, writeImage) stays on the
+ * host side of the boundary.
+ *
+ * Conventions: plain C types, caller-owned buffers, every function returns
+ * RT_OK (0) or a negative rt_status; no exception crosses the boundary.  A handle
+ * is bound to one HIP device and is not re-entrant (one caller at a time).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context* rt_handle;
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,        /* null pointer, bad size, bad enum                        */
+    RT_ERR_HIP = -2,        /* a HIP runtime call failed (rt_last_error has the text)  */
+    RT_ERR_NO_SCENE = -3,   /* render called before rt_upload_scene                    */
+    RT_ERR_SCENE = -4,      /* scene violates a stated limit (depth, vertex count ...) */
+    RT_ERR_GUARD = -5,      /* a device loop guard tripped: the scene is outside the   */
+                            /* range in which the reference itself terminates          */
+    RT_ERR_NO_DEVICE = -6   /* no gfx950 device / kernels not loadable                 */
+} rt_status;
+
+/* ---- scene tables: the state read_json_scene leaves behind, as flat doubles ----
+ * One record per solid, in file order (order decides ties in the closest-hit scan,
+ * /root/reference/src/main.cpp:34-43, and which emitter is "the first light",
+ * :138-139).  Normals are already normalised, gloss already derived
+ * (readShape.cpp:62-64,73,95). */
+enum { RT_KIND_SPHERE = 0, RT_KIND_PLANE = 1, RT_KIND_FACE = 2 };
+
+/* prim record, RT_PR_STRIDE doubles */
+enum {
+    RT_PR_KIND = 0,    /* RT_KIND_*                                                   */
+    RT_PR_LIGHT = 1,   /* Solid::is_light (geometry.hpp:54); always 0 for planes      */
+    RT_PR_MAT0 = 2,    /* material index (plane: material1)                           */
+    RT_PR_MAT1 = 3,    /* plane: material2, else = MAT0                               */
+    RT_PR_VOFF = 4,    /* face: first vertex in the vertex table                      */
+    RT_PR_VCNT = 5,    /* face: vertex count                                          */
+    RT_PR_A = 6,       /* [3] sphere centre | plane point | face verts[0]             */
+    RT_PR_N = 9,       /* [3] plane / face unit normal                                */
+    RT_PR_RADIUS = 12,
+    RT_PR_STRIDE = 13
+};
+
+/* material record, RT_MT_STRIDE doubles: struct Material, geometry.hpp:18-29 */
+enum {
+    RT_MT_REF = 0,     /* [3] emission                                                */
+    RT_MT_LIGHT = 3,
+    RT_MT_GLOSS = 4,
+    RT_MT_DIFF = 5,    /* [3]                                                         */
+    RT_MT_SPEC = 8,    /* [3]                                                         */
+    RT_MT_SEXP = 11,
+    RT_MT_RDIFF = 12,  /* [3]                                                         */
+    RT_MT_RSPEC = 15,  /* [3]                                                         */
+    RT_MT_RSEXP = 18,
+    RT_MT_RINDEX = 19,
+    RT_MT_STRIDE = 20
+};
+
+/* parameter vector, RT_PA_COUNT doubles: the header object of the scene stream */
+enum {
+    RT_PA_WIDTH = 0, RT_PA_HEIGHT, RT_PA_SPP, RT_PA_DEPTH, RT_PA_THREADS, RT_PA_BLURS,
+    RT_PA_SCALE, RT_PA_LENS, RT_PA_FOCAL, RT_PA_EXPOSURE,
+    RT_PA_SEED,        /* frame seed mixed into every pixel's RNG seed (0 by default) */
+    RT_PA_COUNT
+};
+
+/* limits */
+#define RT_MAX_DEPTH 16          /* max_ray_depth accepted by rt_upload_scene           */
+#define RT_MAX_FACE_VERTS 64
+
+typedef struct {
+    double upload_ms;      /* last rt_upload_scene: table flattening + H2D              */
+    double kernel_ms;      /* last render: device time of the render kernel (HIP events)*/
+    double total_ms;       /* last rt_render: kernel + D2H of the outputs               */
+    uint64_t rays;         /* last render: ray segments traced (reference: num_rays)    */
+    uint64_t candidates;   /* last render: (ray, solid) pairs the FP32 broad phase kept */
+                           /* for the exact FP64 test                                    */
+    uint64_t sphere_tests; /* last render: rays x spheres, etc. (roofline numerators)   */
+    uint64_t plane_tests;
+    uint64_t face_tests;
+    uint64_t face_vert_tests;
+} rt_timing;
+
+/* Create a context on HIP device `device` (index as HIP enumerates it).
+ * Replaces: the allocation block of main(), main.cpp:300-303. */
+int rt_create(rt_handle* out, int device);
+
+/* Free device buffers and the context.  Replaces main.cpp:328-331. */
+void rt_destroy(rt_handle h);
+
+/* Copy the scene into device tables (float structure-of-arrays, file order kept).
+ * params: RT_PA_COUNT doubles; prims: n_prims*RT_PR_STRIDE; mats: n_mats*RT_MT_STRIDE;
+ * verts: n_verts*3.  Replaces: objs = *read_json_scene(...) and the globals it sets,
+ * main.cpp:292, readShape.cpp:31-42. */
+int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double* prims, int n_mats,
+                    const double* mats, int n_verts, const double* verts);
+
+/* Number of image rows rank `rank` of `world` owns under the cyclic row-tile
+ * partition (tile k = rows [k*tile_rows, (k+1)*tile_rows) belongs to rank k % world).
+ * The reference's own partition is the special case tile_rows = 1, world = num_threads
+ * (main.cpp:250). */
+int rt_rows_for_rank(int height, int tile_rows, int rank, int world);
+
+/* Render this rank's rows into DEVICE memory, asynchronously on `stream`
+ * (a hipStream_t, or NULL for the default stream).  One RNG stream per pixel, seeded
+ * from the pixel's index in the full frame, so the result does not depend on the
+ * partition.
+ *   d_rgb     : double[rows*width*3], the rank's rows packed in ascending row order;
+ *               un-exposed radiance, the reference's Color colors[] (main.cpp:275,303)
+ *   d_hit_ids : optional int32[rows*width*spp]: file index of the solid each camera
+ *               ray hit, -1 for none (the hit/miss mask); NULL to skip
+ * Replaces: the thread fan-out main.cpp:304-313 around do_rays_i. */
+int rt_render_rows_device(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids,
+                          void* stream);
+
+/* Reference-order validation mode: one GPU lane per reference thread.  Lane t renders
+ * rows t, t+T, ... (T = num_threads of the scene header) pixel after pixel from ONE
+ * RNG stream started at state 1, exactly the order of main.cpp:250-253,301,307, so the
+ * frame can be compared with the reference binary's own output.  Slow by design.
+ *   d_rgb: double[height*width*3] (whole frame); d_hit_ids as above, whole frame. */
+int rt_render_streams_device(rt_handle h, double* d_rgb, int32_t* d_hit_ids, void* stream);
+
+/* Wait for the last render on this context, check the device guard word and return
+ * the number of ray segments traced by it (reference: the sum main.cpp:321-324). */
+int rt_finish(rt_handle h, uint64_t* rays);
+
+/* Per-stream ray counters of the last stream-mode render (reference: long num_rays[T],
+ * main.cpp:300,127).  Call after rt_finish; n <= num_threads. */
+int rt_stream_rays(rt_handle h, uint64_t* out, int n);
+
+/* Convenience: whole frame on this device, outputs copied to HOST buffers.
+ *   rgb: double[height*width*3]; rays: out; hit_ids: optional int32[height*width*spp]. */
+int rt_render(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids);
+int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids);
+
+/* Timing and work counters of the last upload/render (HIP-event device time). */
+int rt_last_timing(rt_handle h, rt_timing* out);
+
+/* Text of the last error on this context (never NULL). */
+const char* rt_last_error(rt_handle h);
+
+/* Kernel self-tests used by the parity suite: evaluate the device math on n inputs.
+ * fn: 0 sin, 1 cos, 2 acos, 3 pow(x,y), 4 x/y, 5 sqrt(x), 6 next RNG state (state passed
+ * in the low 32 bits of x's bit pattern).  x, y, out are HOST double arrays. */
+int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* y, double* out);
+
+/* Broad-phase self-test: for n independent (ray, bounding sphere) pairs evaluate the FP32
+ * conservative test exactly as the render kernel does.  flags[i]: 0 = dropped, 1 = kept for
+ * the exact test, 2 = dropped as wholly behind the origin.  Host arrays: origins, dirs,
+ * centres are double[n*3], radii double[n]. */
+int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* dirs, const double* centres,
+                      const double* radii, int32_t* flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -7,7 +7,7 @@ using namespace rto;
 
 extern "C" {
 
-// policy: 0 = RefPolicy (double, libm), 1 = DevPolicy (float, portable math).
+// policy: 0 = RefPolicy (double, libm), 1 = DevPolicy (double, portable sin/cos/acos/pow).
 // rng_mode: 0 = per-thread streams (the reference's order), 1 = per-pixel streams.
 // Returns 0, -1 if a loop guard tripped (scene outside the reference's defined
 // behaviour), -2 on bad arguments.
@@ -34,7 +34,7 @@ void oracle_rng_stream(uint32_t state, int n, uint32_t* out) {
 }
 
 // fn: 0 sin, 1 cos, 2 acos, 3 pow(x,y)
-void oracle_math(int fn, int n, const float* x, const float* y, float* out) {
+void oracle_math(int fn, int n, const double* x, const double* y, double* out) {
     for (int i = 0; i < n; i++) {
         switch (fn) {
             case 0: out[i] = orm::p_sin(x[i]); break;

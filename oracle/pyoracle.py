@@ -45,7 +45,7 @@ def lib():
         l.oracle_rng_stream.restype = None
         l.oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         l.oracle_math.restype = None
-        l.oracle_math.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.oracle_math.argtypes = [C.c_int, C.c_int, dp, dp, dp]
         _lib = l
     return _lib
 
@@ -107,12 +107,10 @@ def rng_stream(state, n):
 
 
 def math_fn(fn, x, y=None):
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
     out = np.zeros_like(x)
-    fp = C.POINTER(C.c_float)
-    lib().oracle_math({"sin": 0, "cos": 1, "acos": 2, "pow": 3}[fn], x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp),
-                      out.ctypes.data_as(fp))
+    lib().oracle_math({"sin": 0, "cos": 1, "acos": 2, "pow": 3}[fn], x.size, _dp(x), _dp(y), _dp(out))
     return out
 
 

@@ -12,10 +12,12 @@
 //              rng_mode = STREAM this reproduces the compiled reference bit for
 //              bit (pinned by tests/test_oracle_vs_reference.py against
 //              oracle/_ref and by the committed fixtures under tests/golden/).
-//   DevPolicy  float, the portable functions of rt_oracle_math.hpp, dot products
-//              and point+t*dir evaluated with fused multiply-add.  This is the
-//              arithmetic the GPU kernels implement; the parity tests compare
-//              the kernels with this instantiation bit for bit.
+//   DevPolicy  RefPolicy with libm's sin, cos, acos and pow replaced by the portable
+//              functions of rt_oracle_math.hpp -- nothing else differs.  This is
+//              the arithmetic the GPU kernels implement (a GPU cannot reproduce
+//              glibc bit for bit); the parity tests compare the kernels with this
+//              instantiation bit for bit, and DevPolicy with RefPolicy / the
+//              reference's golden images statistically.
 //
 // and over a run-time RNG mode:
 //
@@ -91,16 +93,15 @@ struct RefPolicy {
 };
 
 struct DevPolicy {
-    typedef float Real;
+    typedef double Real;
     static const bool is_ref = false;
-    static Real madd(Real acc, Real a, Real b) { return __builtin_fmaf(a, b, acc); }
+    static Real madd(Real acc, Real a, Real b) { return acc + a * b; }
     static Real sin(Real x) { return orm::p_sin(x); }
     static Real cos(Real x) { return orm::p_cos(x); }
     static Real acos(Real x) { return orm::p_acos(x); }
     static Real pow(Real x, Real y) { return orm::p_pow(x, y); }
-    static Real sqrt(Real x) { return __builtin_sqrtf(x); }
-    // the same decision as RefPolicy, taken in double on the loader's double gloss
-    // (the device carries it as the integer threshold ceil(gloss*max))
+    static Real sqrt(Real x) { return __builtin_sqrt(x); }
+    // same decision as RefPolicy (the device carries it as the integer threshold ceil(gloss*max))
     static bool glossy(uint32_t g, double gloss) { return (double)g < gloss * (double)RNG_MAX; }
 };
 

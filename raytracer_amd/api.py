@@ -1,0 +1,212 @@
+"""ctypes binding of librt_hip.so (include/rt_hip.h) and the host-side render call.
+
+Mirrors the host sequence of the reference's main()
+(/root/reference/src/main.cpp:291-333): load scene -> render every pixel ->
+expose -> write image, with the thread fan-out around do_rays_i replaced by one
+call into the HIP library.  There is no CPU fallback: without the library or a
+GPU every render call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scene as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librt_hip.so")
+
+RT_OK = 0
+STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE", -4: "RT_ERR_SCENE",
+          -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}
+
+EXPORTS = ("rt_create", "rt_destroy", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
+           "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams",
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"{STATUS.get(code, code)}: {text}")
+        self.code = code
+
+
+class RtTiming(C.Structure):
+    _fields_ = [("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("rays", C.c_uint64), ("candidates", C.c_uint64), ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
+                ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load librt_hip.so and declare its prototypes.  Raises if it is missing: the HIP
+    library is the only implementation of the render path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RtError(-6, f"{path} not found: build it with `make -C raytracer_amd/csrc` (python -c 'import __graft_entry__ as g; g.build()')")
+    l = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    l.rt_create.restype = C.c_int
+    l.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    l.rt_destroy.restype = None
+    l.rt_destroy.argtypes = [C.c_void_p]
+    l.rt_upload_scene.restype = C.c_int
+    l.rt_upload_scene.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
+    l.rt_rows_for_rank.restype = C.c_int
+    l.rt_rows_for_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    l.rt_render_rows_device.restype = C.c_int
+    l.rt_render_rows_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.rt_render_streams_device.restype = C.c_int
+    l.rt_render_streams_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.rt_finish.restype = C.c_int
+    l.rt_finish.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    l.rt_stream_rays.restype = C.c_int
+    l.rt_stream_rays.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    for f in (l.rt_render, l.rt_render_streams):
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    l.rt_last_timing.restype = C.c_int
+    l.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(RtTiming)]
+    l.rt_last_error.restype = C.c_char_p
+    l.rt_last_error.argtypes = [C.c_void_p]
+    l.rt_selftest_math.restype = C.c_int
+    l.rt_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
+    l.rt_selftest_broad.restype = C.c_int
+    l.rt_selftest_broad.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+    _lib = l
+    return l
+
+
+def rows_for_rank(height, tile_rows, rank, world):
+    return load_library().rt_rows_for_rank(height, tile_rows, rank, world)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Renderer:
+    """One rt_handle bound to one GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.rt_create(C.byref(self.h), int(device))
+        if rc != RT_OK:
+            raise RtError(rc, "rt_create failed (no usable gfx950 device?)")
+        self.scene = None
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.rt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, sc: S.Scene):
+        params = sc.params()
+        prims = np.ascontiguousarray(sc.prims, dtype=np.float64)
+        mats = np.ascontiguousarray(sc.mats, dtype=np.float64)
+        verts = np.ascontiguousarray(sc.verts, dtype=np.float64)
+        self._check(self.lib.rt_upload_scene(self.h, _dp(params), len(prims), _dp(prims) if len(prims) else None,
+                                             len(mats), _dp(mats) if len(mats) else None,
+                                             len(verts), _dp(verts) if len(verts) else None))
+        self.scene = sc
+
+    def render(self, want_hits=False, streams=False):
+        """Whole frame, outputs on the host: dict(rgb=float64[H,W,3], rays=int, hits=int32[H,W,spp]|None).
+        streams=True renders in the reference's RNG order (one lane per reference thread; validation mode)
+        and adds stream_rays=uint64[num_threads]."""
+        sc = self.scene
+        if sc is None:
+            raise RtError(-3, "no scene uploaded")
+        rgb = np.zeros((sc.height, sc.width, 3), dtype=np.float64)
+        hits = np.full((sc.height, sc.width, sc.spp), -2, dtype=np.int32) if want_hits else None
+        rays = C.c_uint64(0)
+        fn = self.lib.rt_render_streams if streams else self.lib.rt_render
+        self._check(fn(self.h, _dp(rgb), C.byref(rays), hits.ctypes.data_as(C.POINTER(C.c_int32)) if want_hits else None))
+        out = dict(rgb=rgb, rays=int(rays.value), hits=hits)
+        if streams:
+            T = int(sc.header["num_threads"])
+            sr = np.zeros(T, dtype=np.uint64)
+            self._check(self.lib.rt_stream_rays(self.h, sr.ctypes.data_as(C.POINTER(C.c_uint64)), T))
+            out["stream_rays"] = sr
+        return out
+
+    def render_rows_device(self, d_rgb_ptr, tile_rows, rank, world, d_hits_ptr=None, stream=None):
+        """Asynchronous render of this rank's row tiles into device memory (raw pointers)."""
+        self._check(self.lib.rt_render_rows_device(self.h, int(tile_rows), int(rank), int(world), C.c_void_p(d_rgb_ptr),
+                                                   C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
+                                                   C.c_void_p(stream) if stream else None))
+
+    def finish(self):
+        rays = C.c_uint64(0)
+        self._check(self.lib.rt_finish(self.h, C.byref(rays)))
+        return int(rays.value)
+
+    def timing(self):
+        t = RtTiming()
+        self._check(self.lib.rt_last_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in RtTiming._fields_}
+
+    def selftest_math(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
+        out = np.zeros_like(x)
+        code = {"sin": 0, "cos": 1, "acos": 2, "pow": 3, "div": 4, "sqrt": 5, "rng": 6}[fn]
+        self._check(self.lib.rt_selftest_math(self.h, code, x.size, _dp(x), _dp(y), _dp(out)))
+        return out
+
+    def selftest_broad(self, origins, dirs, centres, radii):
+        o = np.ascontiguousarray(origins, dtype=np.float64); d = np.ascontiguousarray(dirs, dtype=np.float64)
+        c = np.ascontiguousarray(centres, dtype=np.float64); r = np.ascontiguousarray(radii, dtype=np.float64)
+        flags = np.zeros(len(r), dtype=np.int32)
+        self._check(self.lib.rt_selftest_broad(self.h, len(r), _dp(o), _dp(d), _dp(c), _dp(r), flags.ctypes.data_as(C.POINTER(C.c_int32))))
+        return flags
+
+
+# ------------------------------------------------------------------ host post-process
+def expose(rgb: np.ndarray, exposure: float, num_blurs: int) -> np.ndarray:
+    """expose() + blur() + Color::to_int of the reference (main.cpp:186-242,
+    geometry.cpp:15-23) on the host in float64: bloom of over-exposed pixels through
+    num_blurs passes of the 41x41 Gaussian (radius 20, sigma 3, zero outside the frame,
+    taps summed ky-outer / kx-inner) and truncating 8-bit pack 0xRRGGBB.
+    Returns int32[H,W]."""
+    H, W, _ = rgb.shape
+    col = rgb.astype(np.float64)
+    radius, stddev = 20, 3.0
+    denom = 2 * stddev * stddev
+    import math
+    kernel = np.array([[math.exp(-(x * x + y * y) / denom) / denom / math.pi for x in range(-radius, radius + 1)]
+                       for y in range(-radius, radius + 1)], dtype=np.float64)
+    cur = np.where(col * exposure > 1, float(exposure), 0.0)
+    for _ in range(int(num_blurs)):
+        pad = np.zeros((H + 2 * radius, W + 2 * radius, 3), dtype=np.float64)
+        pad[radius:radius + H, radius:radius + W] = cur
+        nxt = np.zeros_like(cur)
+        # same tap order as the reference: ky outer, kx inner, one rounded product and one rounded sum per tap
+        for ky in range(2 * radius + 1):
+            for kx in range(2 * radius + 1):
+                nxt = nxt + pad[ky:ky + H, kx:kx + W] * kernel[ky, kx]
+        cur = nxt
+    col = col + cur
+    mx = 1.0 / exposure
+    with np.errstate(invalid="ignore", over="ignore"):
+        v = (255 * col / mx)
+        iv = np.where(np.isfinite(v), np.trunc(np.clip(v, -2147483648.0, 2147483647.0)), -2147483648.0).astype(np.int64)
+    iv = np.minimum(iv, 255)
+    return ((iv[..., 0] << 16) + (iv[..., 1] << 8) + iv[..., 2]).astype(np.int32)

@@ -1,0 +1,1152 @@
+// librt_hip.so -- render kernels for gfx950 (MI355X) and their C ABI (include/rt_hip.h).
+//
+// What is computed: the per-pixel render loop of samkottler/rayTracer,
+// /root/reference/src/main.cpp:247-289 (do_rays_i) with everything it calls:
+// add_to_path :126-183, get_intersection :34-43, get_reflection_ray :47-104,
+// get_refraction_ray :107-122, the primitives of /root/reference/src/geometry.cpp
+// :94-179 and the shading product Path::trace :186-217.
+//
+// How it is organised on the GPU:
+//   * one lane owns one pixel at a time and runs its paths_per_pixel paths in
+//     order from a per-pixel minstd_rand0 stream (the reference's generator,
+//     seeded per pixel instead of per CPU thread);
+//   * lanes are persistent: a lane whose pixel is finished takes the next pixel
+//     from a global queue (one ballot + one atomic per wave, the new work packed
+//     into the idle lanes by their rank in the ballot), and a lane whose path ended
+//     starts its next camera ray at once -- so every lane that enters the
+//     closest-hit scan carries a live ray, whatever its neighbours' path lengths;
+//   * closest hit (get_intersection) is split in two:
+//       broad phase, FP32, the hot loop: every primitive has a bounding sphere
+//         (a sphere is its own; a face gets the sphere around its vertices; a plane
+//         an infinite one) stored as one float4 in LDS, in file order.  All lanes
+//         of a wave read the same record (LDS broadcast) and evaluate a
+//         conservative ray/sphere discriminant in 10 VALU instructions; the error
+//         bound of the float evaluation is folded into per-ray and per-record
+//         constants, so a primitive the exact test could accept is never dropped.
+//         Survivors (a handful per ray) are appended to a per-lane candidate list;
+//       narrow phase, FP64: the candidates are evaluated in file order with the
+//         reference's own double-precision operation sequence (no fused
+//         multiply-add, IEEE divide and sqrt), including its acceptance rule on
+//         Euclidean distance and its tie order;
+//   * lists larger than the LDS window are streamed through it in chunks with the
+//     workgroup in lock-step; smaller lists are staged once and the waves run free;
+//   * the reference's recursion and linked vertex list become a loop and a
+//     per-lane stack of per-vertex throughput factors, multiplied light-to-camera
+//     at the end exactly as Path::trace does.
+//
+// Arithmetic contract: outside the broad phase every value is a double and every
+// operation is the reference's, rounded separately (-ffp-contract=off), so results
+// are reproducible bit for bit on a CPU; only sin/cos/acos/pow differ from the
+// reference binary (rt_math.h instead of glibc).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_math.h"
+
+namespace {
+
+// ------------------------------------------------------------------ device data
+constexpr double RT_EPS = 0.001;               // Sphere/Plane::intersect, geometry.cpp:102,135-136
+constexpr int RT_MAXV = 2 * RT_MAX_DEPTH + 2;  // bounce-stack entries per lane
+constexpr int BROAD_UNROLL = 4;
+constexpr int CAND_CAP = 48;                   // candidate list entries per lane before an early narrow phase
+constexpr unsigned ERR_REJECT_GUARD = 1u, ERR_STACK = 2u;
+constexpr int REJECT_GUARD_ITERS = 1 << 20;
+constexpr float F32_U = 5.9604645e-8f;         // 2^-24, unit roundoff of float
+
+struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to BROAD_UNROLL
+
+struct PrimD {               // 96 bytes, indexed by file order: the narrow phase's exact data
+    double a[3];             // sphere centre | plane point | face verts[0]
+    double radius;
+    double n[3];             // plane / face unit normal
+    int kind, mat0, mat1, voff;
+    int vcnt, pad0, pad1, pad2;
+};
+
+struct MatD {                // struct Material (geometry.hpp:18-29) in double
+    double ref[3], diff[3], spec[3], rdiff[3], rspec[3];
+    double sexp, rindex;
+    unsigned is_light;
+    unsigned gloss_thr;      // glossy iff rng < gloss_thr  (= ceil(gloss * 2147483646), main.cpp:48)
+};
+
+struct KParams {
+    int width, height, spp, depth;
+    double scale, lens, focal;
+    unsigned frame_seed;
+    int has_light, light_draws;
+    int tile_rows, rank, world;
+    int stream_mode, n_streams;
+    unsigned total_items;
+    int nchunks;
+    float cmax;              // max |C - T| + R over finite bounding spheres
+    double T[3];             // translation applied before rounding coordinates to float
+    const float4* records;
+    const ChunkDesc* chunks;
+    const PrimD* prims;
+    const double* verts;
+    const MatD* mats;
+    double* rgb;
+    int* hit_ids;
+    unsigned long long* stream_rays;
+    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64)
+};
+
+struct d3 { double x, y, z; };
+
+#define DEV __device__ __forceinline__
+
+DEV d3 dmk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV d3 dsub(d3 a, d3 b) { return dmk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV d3 dadd(d3 a, d3 b) { return dmk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV d3 dscale(d3 a, double s) { return dmk(s * a.x, s * a.y, s * a.z); }
+DEV d3 dneg(d3 a) { return dmk(-a.x, -a.y, -a.z); }
+// Vector::dot, Vector.cpp:33-39: total = 0; total += a[i]*b[i], every step rounded
+DEV double ddot(d3 a, d3 b) {
+    double t = 0.0;
+    t = t + a.x * b.x;
+    t = t + a.y * b.y;
+    t = t + a.z * b.z;
+    return t;
+}
+DEV double dlen(d3 a) { return __builtin_sqrt(ddot(a, a)); }
+DEV d3 dnorm(d3 a) { double l = dlen(a); return dmk(a.x / l, a.y / l, a.z / l); }
+DEV d3 dcross(d3 a, d3 b) {
+    return dmk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// Point + t*direction, geometry.cpp:55-57 after Vector.cpp:67-69: product, then sum
+DEV d3 dalong(d3 o, double t, d3 d) { return dmk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z); }
+DEV bool dnan(double x) { return x != x; }
+// Point::is_valid, geometry.cpp:51-54
+DEV bool dvalid(d3 p) {
+    const double inf = __builtin_inf();
+    return !(dnan(p.x) || dnan(p.y) || dnan(p.z) || p.x == inf || p.y == inf || p.z == inf);
+}
+
+// minstd_rand0: x <- 16807 x mod (2^31 - 1), by folding the 46-bit product (2^31 == 1 mod m)
+DEV unsigned rng_next(unsigned& s) {
+    unsigned long long p = (unsigned long long)s * 16807ull;
+    unsigned x = (unsigned)(p & 0x7fffffffull) + (unsigned)(p >> 31);
+    if (x >= 0x7fffffffu) x -= 0x7fffffffu;
+    s = x;
+    return x;
+}
+// (double)g() / g.max(), main.cpp:255
+DEV double rng_uniform(unsigned& s) { return (double)rng_next(s) / 2147483646.0; }
+
+__host__ __device__ inline unsigned pixel_seed(unsigned pixel_index, unsigned frame_seed) {
+    unsigned h = pixel_index * 0x9E3779B1u ^ frame_seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return 1u + (h % 2147483646u);
+}
+
+struct Hit {
+    double len;     // |p - o| of the closest accepted hit so far (get_intersection's criterion)
+    int idx;        // file index of its solid, -1 = none
+    d3 p;
+};
+
+// get_intersection's acceptance, main.cpp:37
+DEV void consider(d3 p, int idx, d3 o, Hit& h) {
+    if (!dvalid(p)) return;
+    double len = dlen(dsub(p, o));
+    if (h.len > len) { h.len = len; h.idx = idx; h.p = p; }
+}
+
+// Sphere::intersect, geometry.cpp:129-138
+DEV d3 sphere_point(const PrimD& s, d3 o, d3 d) {
+    d3 oc = dsub(o, dmk(s.a[0], s.a[1], s.a[2]));
+    double b = 2.0 * ddot(d, oc);
+    double c = ddot(oc, oc) - s.radius * s.radius;
+    double sq = __builtin_sqrt(b * b - 4.0 * c);
+    double t = (-b - sq) / 2.0;
+    if (t < RT_EPS) t = (-b + sq) / 2.0;
+    if (t < RT_EPS) t = __builtin_nan("");
+    return dalong(o, t, d);
+}
+// Plane::intersect, geometry.cpp:99-105
+DEV d3 plane_point(d3 P, d3 n, d3 o, d3 d) {
+    double t = ddot(dsub(P, o), n) / ddot(n, d);
+    const double inf = __builtin_inf();
+    if (t < RT_EPS) t = __builtin_nan("");
+    if (t == inf || t == -inf) t = __builtin_nan("");
+    return dalong(o, t, d);
+}
+// Face::intersect, geometry.cpp:160-168
+DEV d3 face_point(const PrimD& f, const double* verts, d3 o, d3 d) {
+    d3 p = plane_point(dmk(f.a[0], f.a[1], f.a[2]), dmk(f.n[0], f.n[1], f.n[2]), o, d);
+    const int num = f.vcnt;
+    const double* v = verts + (size_t)f.voff * 3;
+    bool miss = false;
+    for (int i = 0; i < num; i++) {
+        const int i1 = (i + 1 < num) ? i + 1 : i + 1 - num;
+        const int i2 = (i + 2) % num;
+        d3 vi = dmk(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+        d3 e = dsub(vi, dmk(v[3 * i1], v[3 * i1 + 1], v[3 * i1 + 2]));
+        double to_p = ddot(e, dsub(vi, p));
+        double to_next = ddot(e, dsub(vi, dmk(v[3 * i2], v[3 * i2 + 1], v[3 * i2 + 2])));
+        if (to_p * to_next < 0.0) miss = true;
+    }
+    if (miss) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+    return p;
+}
+
+// Line::reflect, geometry.cpp:78-83: 2 (n.d) n - d
+DEV d3 reflect_dir(d3 d, d3 n) {
+    d3 w = dscale(n, ddot(n, d));
+    return dsub(dscale(w, 2.0), d);
+}
+
+// rotation of a +z hemisphere sample v about the unit axis n, main.cpp:73,100
+DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
+    double nv = ddot(n, v);
+    d3 a = dscale(dsub(v, dscale(n, nv)), cost);
+    d3 b = dscale(n, nv);
+    d3 c = dscale(dcross(n, v), sint);
+    return dadd(dadd(a, b), c);
+}
+
+// get_reflection_ray, main.cpp:47-104.  Returns the new direction (not re-normalised).
+DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* err) {
+    const double PI = 3.14159265358979323846;
+    const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
+    if (rng_next(rng) < m.gloss_thr) {
+        d3 r = dneg(reflect_dir(d, normal));
+        double theta = rtm::acosd(r.z);
+        d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), r));
+        double sint, cost;
+        rtm::sincosd(theta, &sint, &cost);
+        const double inv_exp = 1.0 / m.sexp;
+        d3 nd = dmk(0.0, 0.0, 0.0);
+        for (int iter = 0;; iter++) {
+            double u = rtm::powd(rtm::cosd(rng_uniform(rng) * PI / 2.0), inv_exp);
+            double phi = rng_uniform(rng) * 2.0 * PI;
+            double sr = __builtin_sqrt(1.0 - u * u);
+            double sp, cp;
+            rtm::sincosd(phi, &sp, &cp);
+            d3 v = dmk(sr * cp, sr * sp, u);
+            nd = flat ? v : rotate3(v, n, cost, sint);
+            if (ddot(nd, normal) >= 0.0) break;
+            if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); break; }
+        }
+        return nd;
+    } else {
+        double theta = rtm::acosd(normal.z);
+        d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), normal));
+        double sint, cost;
+        rtm::sincosd(theta, &sint, &cost);
+        double u = rng_uniform(rng);
+        double phi = rng_uniform(rng) * 2.0 * PI;
+        double sr = __builtin_sqrt(1.0 - u * u);
+        double sp, cp;
+        rtm::sincosd(phi, &sp, &cp);
+        d3 v = dmk(sr * cp, sr * sp, u);
+        return flat ? v : rotate3(v, n, cost, sint);
+    }
+}
+
+// get_refraction_ray, main.cpp:107-122, with Line::reflect / Line::refract, geometry.cpp:78-92
+DEV d3 refraction_dir(d3 d, d3 normal, double rindex, double n_cur) {
+    double n2;
+    d3 an = normal;
+    if (__builtin_fabs(rindex - n_cur) < 0.0001) { n2 = 1.0; an = dneg(normal); }
+    else n2 = rindex;
+    double nv = ddot(an, d);
+    if ((n2 * n2) / (n_cur * n_cur) < 1.0 - nv * nv) return reflect_dir(d, an);
+    double ratio = n_cur / n2;
+    double anv = __builtin_fabs(nv);
+    double k = ratio * anv - __builtin_sqrt(1.0 - ratio * ratio * (1.0 - anv * anv));
+    return dnorm(dadd(dscale(d, ratio), dscale(an, k)));
+}
+
+// Plane::get_material, geometry.cpp:106-116
+DEV int plane_material(const PrimD& pi, d3 p) {
+    double vx = p.x - pi.a[0], vz = p.z - pi.a[2];
+    int x = (int)(vx / 5.0) % 2;
+    int z = (int)(vz / 5.0) % 2;
+    if (vx < 0.0) x = -x;
+    if (vz < 0.0) z = -z;
+    int m = (x == z) ? pi.mat0 : pi.mat1;
+    if ((vx < 0.0) != (vz < 0.0)) m = (x == z) ? pi.mat1 : pi.mat0;
+    return m;
+}
+
+// ---- broad phase ---------------------------------------------------------------------------
+// Per-ray constants of the conservative float test.  With o, c relative to the translation T
+// and rounded to float, d rounded to float:
+//     hb  = d.(o - c)            = od - d.c
+//     oo  = |o - c|^2 - R^2      = o2 + (|c|^2 - R^2) - 2 o.c  = o2 + q
+//     the exact discriminant  hb^2 - oo >= 0  implies   hb~^2 + k1 |hb~| + K - q~ >= 0
+// where hb~, q~ are the float evaluations, k1 = 2 Eh, K = Eh^2 + E0 - o2 (rounded up) and
+//     Eh = 14 u (|o| + cmax)       bounds |hb~ - hb|   (input rounding + 4 roundings, doubled)
+//     E0 = 24 u (|o| + cmax)^2     bounds the error of o2 + q~ and of the last three operations.
+struct Broad {
+    float dx, dy, dz;      // -d
+    float mx, my, mz;      // -2 o
+    float od;              // d.o
+    float k1, K;
+    float behind_h, behind_c;   // sphere wholly behind the origin iff hb~ > behind_h and q~ > behind_c
+};
+
+DEV Broad broad_setup(d3 o, d3 d, const KParams& kp) {
+    Broad b;
+    const float ox = (float)(o.x - kp.T[0]), oy = (float)(o.y - kp.T[1]), oz = (float)(o.z - kp.T[2]);
+    const float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+    const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
+    const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
+    const float S = __builtin_sqrtf((float)o2) * 1.0001f + kp.cmax;
+    const float Eh = 14.0f * F32_U * S;
+    const float E0 = 24.0f * F32_U * S * S;
+    b.dx = -fx; b.dy = -fy; b.dz = -fz;
+    b.mx = -2.0f * ox; b.my = -2.0f * oy; b.mz = -2.0f * oz;
+    b.od = (float)od;
+    b.k1 = 2.0f * Eh * 1.0001f;
+    const double Kd = (double)Eh * Eh + (double)E0 - o2;
+    b.K = (float)Kd + __builtin_fabsf((float)Kd) * (4.0f * F32_U);
+    // wholly behind: true hb >= hb~ - Eh > 0 and true oo >= o2 + q~ - E0 > 0  (origin outside, centre behind)
+    b.behind_h = Eh;
+    b.behind_c = (float)((double)E0 - o2) + __builtin_fabsf((float)o2) * (4.0f * F32_U);
+    return b;
+}
+
+// conservative discriminant of one record; hb and q are returned for the behind test
+DEV float broad_disc(const float4 r, const Broad& b, float& hb, float& q) {
+    hb = __builtin_fmaf(b.dz, r.z, __builtin_fmaf(b.dy, r.y, __builtin_fmaf(b.dx, r.x, b.od)));
+    q = __builtin_fmaf(b.mz, r.z, __builtin_fmaf(b.my, r.y, __builtin_fmaf(b.mx, r.x, r.w)));
+    const float t = b.K - q;
+    const float m = __builtin_fmaf(__builtin_fabsf(hb), b.k1, t);
+    return __builtin_fmaf(hb, hb, m);
+}
+
+enum { ST_NEED = 0, ST_ALIVE = 1, ST_DEAD = 2 };
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
+    extern __shared__ float4 lds[];
+    const int lane = threadIdx.x & 63;
+    const bool lockstep = kp.nchunks > 1;
+    const double PI = 3.14159265358979323846;
+
+    // ---- per-lane state
+    int state = ST_NEED;
+    unsigned item = 0;        // pixel mode: local pixel index; stream mode: stream number
+    unsigned out_index = 0;   // pixel slot in rgb / hit_ids
+    int px = 0, py = 0;
+    unsigned rng = 1;
+    int sample = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    d3 o = dmk(0, 0, 0), d = dmk(0, 0, 1);
+    int remaining = 0;
+    double n_cur = 1.0;
+    int nverts = 0;
+    bool first_seg = false;
+    d3 pv_p = dmk(0, 0, 0), pv_n = dmk(0, 0, 0), pv_r = dmk(0, 0, 0);
+    int pv_mat = 0;
+    bool pv_reflect = false;
+    unsigned nrays = 0, ncand_total = 0;
+    unsigned long long item_rays = 0;
+    double fst[RT_MAXV * 3];
+    int cand[CAND_CAP];
+
+    auto stage = [&](int c) {
+        const ChunkDesc ch = kp.chunks[c];
+        const float4* src = kp.records + ch.gofs;
+        for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
+    };
+
+    // the camera ray of do_rays_i, main.cpp:255-270
+    auto start_path = [&]() {
+        double xs = rng_uniform(rng) - 0.5;
+        double ys = rng_uniform(rng) - 0.5;
+        d3 pix = dmk((double)(px - kp.width / 2 + xs) / kp.scale, (double)(kp.height / 2 - py + ys) / kp.scale, 0.0);
+        double theta = rng_uniform(rng) * 2.0 * PI;
+        double rad = rng_uniform(rng) * kp.lens;
+        double st, ct;
+        rtm::sincosd(theta, &st, &ct);
+        const d3 camera = dmk(0.0, 0.0, 40.0);
+        d3 org = dmk(camera.x + rad * ct, camera.y + rad * st, camera.z + 0.0);
+        d3 D = dnorm(dsub(pix, camera));
+        d3 C = dalong(camera, kp.focal, D);
+        o = org;
+        d = dnorm(dsub(C, org));
+        remaining = kp.depth;
+        n_cur = 1.0;
+        nverts = 0;
+        first_seg = true;
+    };
+
+    auto begin_pixel = [&]() {
+        out_index = kp.stream_mode ? (unsigned)(py * kp.width + px) : item;
+        sample = 0;
+        acc0 = acc1 = acc2 = 0.0;
+        start_path();
+    };
+
+    // a path ended with radiance (c0,c1,c2): main.cpp:271-275
+    auto end_path = [&](double c0, double c1, double c2) {
+        acc0 = acc0 + c0; acc1 = acc1 + c1; acc2 = acc2 + c2;
+        sample++;
+        if (sample < kp.spp) {
+            start_path();
+            return;
+        }
+        const double n = (double)kp.spp;
+        double* out = kp.rgb + (size_t)out_index * 3;
+        out[0] = acc0 / n; out[1] = acc1 / n; out[2] = acc2 / n;
+        if (kp.stream_mode) {
+            // next pixel of this reference thread: x ascending, then y += num_threads (main.cpp:250-251)
+            px++;
+            if (px >= kp.width) { px = 0; py += kp.n_streams; }
+            if (py < kp.height) { begin_pixel(); return; }
+            kp.stream_rays[item] = item_rays;
+        }
+        state = ST_NEED;
+    };
+
+    if (!lockstep) {
+        stage(0);
+        __syncthreads();
+    }
+
+    for (;;) {
+        // ---- refill idle lanes from the work queue: one atomic per wave, work packed by ballot rank
+        {
+            const bool need = (state == ST_NEED);
+            const unsigned long long m = __ballot(need);
+            if (m != 0ull) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&kp.ctrl[0], (unsigned)__popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (need) {
+                    item = base + rank;
+                    if (item < kp.total_items) {
+                        if (kp.stream_mode) {
+                            px = 0; py = (int)item;
+                            rng = 1;                                   // default-constructed / seed(0): state 1
+                            item_rays = 0;
+                        } else {
+                            const int lr = (int)(item / (unsigned)kp.width);
+                            px = (int)(item - (unsigned)lr * (unsigned)kp.width);
+                            py = ((lr / kp.tile_rows) * kp.world + kp.rank) * kp.tile_rows + lr % kp.tile_rows;
+                            rng = pixel_seed((unsigned)(py * kp.width + px), kp.frame_seed);
+                        }
+                        if (py < kp.height) { state = ST_ALIVE; begin_pixel(); }
+                        else { if (kp.stream_mode) kp.stream_rays[item] = 0; state = ST_NEED; }
+                    } else {
+                        state = ST_DEAD;
+                    }
+                }
+            }
+        }
+        const bool alive = (state == ST_ALIVE);
+        if (lockstep) {
+            if (!__syncthreads_or(alive ? 1 : 0)) {
+                if (__syncthreads_or(state == ST_NEED ? 1 : 0)) continue;   // stream-mode lanes that got an empty stream
+                break;
+            }
+        } else {
+            if (__ballot(alive) == 0ull) {
+                if (__ballot(state == ST_NEED) != 0ull) continue;
+                break;
+            }
+        }
+
+        // ---- closest hit (get_intersection, main.cpp:34-43)
+        Hit h;
+        h.len = __builtin_inf(); h.idx = -1;
+        h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+        int ncand = 0;
+
+        // narrow phase: the reference's double-precision test on every candidate, in file order
+        auto narrow = [&]() {
+            for (int k = 0; k < ncand; k++) {
+                const int idx = cand[k];
+                const PrimD pr = kp.prims[idx];
+                d3 p0;
+                if (pr.kind == RT_KIND_SPHERE) p0 = sphere_point(pr, o, d);
+                else if (pr.kind == RT_KIND_PLANE) p0 = plane_point(dmk(pr.a[0], pr.a[1], pr.a[2]), dmk(pr.n[0], pr.n[1], pr.n[2]), o, d);
+                else p0 = face_point(pr, kp.verts, o, d);
+                consider(p0, idx, o, h);
+            }
+            ncand_total += (unsigned)ncand;
+            ncand = 0;
+        };
+
+        Broad bp;
+        if (alive) bp = broad_setup(o, d, kp);
+        for (int c = 0; c < kp.nchunks; c++) {
+            if (lockstep) {
+                if (c > 0) __syncthreads();
+                stage(c);
+                __syncthreads();
+            }
+            if (alive) {
+                const ChunkDesc ch = kp.chunks[c];
+                for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
+                    const float4 r0 = lds[i], r1 = lds[i + 1], r2 = lds[i + 2], r3 = lds[i + 3];
+                    float hb0, hb1, hb2, hb3, q0, q1, q2, q3;
+                    const float d0 = broad_disc(r0, bp, hb0, q0);
+                    const float d1 = broad_disc(r1, bp, hb1, q1);
+                    const float d2 = broad_disc(r2, bp, hb2, q2);
+                    const float d3_ = broad_disc(r3, bp, hb3, q3);
+                    if ((d0 >= 0.0f) | (d1 >= 0.0f) | (d2 >= 0.0f) | (d3_ >= 0.0f)) {
+                        const int base = ch.first_index + i;
+                        if (d0 >= 0.0f && !(hb0 > bp.behind_h && q0 > bp.behind_c)) cand[ncand++] = base;
+                        if (d1 >= 0.0f && !(hb1 > bp.behind_h && q1 > bp.behind_c)) cand[ncand++] = base + 1;
+                        if (d2 >= 0.0f && !(hb2 > bp.behind_h && q2 > bp.behind_c)) cand[ncand++] = base + 2;
+                        if (d3_ >= 0.0f && !(hb3 > bp.behind_h && q3 > bp.behind_c)) cand[ncand++] = base + 3;
+                        if (ncand > CAND_CAP - BROAD_UNROLL) narrow();
+                    }
+                }
+            }
+        }
+
+        // ---- one segment of add_to_path, main.cpp:126-183
+        if (alive) {
+            narrow();
+            nrays++;
+            item_rays++;
+            const bool hit = h.idx >= 0;
+            if (first_seg) {
+                if (kp.hit_ids) kp.hit_ids[(size_t)out_index * kp.spp + sample] = h.idx;
+                first_seg = false;
+            }
+            if (!hit) {
+                end_path(0.0, 0.0, 0.0);                                     // main.cpp:179-182
+            } else {
+                const PrimD pi = kp.prims[h.idx];
+                d3 normal;
+                int mi;
+                if (pi.kind == RT_KIND_SPHERE) { normal = dnorm(dsub(h.p, dmk(pi.a[0], pi.a[1], pi.a[2]))); mi = pi.mat0; }
+                else if (pi.kind == RT_KIND_PLANE) { normal = dmk(pi.n[0], pi.n[1], pi.n[2]); mi = plane_material(pi, h.p); }
+                else { normal = dmk(pi.n[0], pi.n[1], pi.n[2]); mi = pi.mat0; }
+                const MatD* m = kp.mats + mi;
+                const bool is_light = m->is_light != 0;
+                const bool dead_end = (!is_light) && remaining == 0 && kp.has_light;   // main.cpp:137-153: always black
+
+                // throughput factor of the previous vertex, Path::trace geometry.cpp:190-213
+                if (nverts > 0 && !dead_end) {
+                    const MatD* pm = kp.mats + pv_mat;
+                    d3 w = dnorm(dsub(h.p, pv_p));
+                    double s;
+                    const double *dc, *sc;
+                    if (pv_reflect) { s = rtm::powd(ddot(pv_r, w), pm->sexp); dc = pm->diff; sc = pm->spec; }
+                    else { s = 1.0; dc = pm->rdiff; sc = pm->rspec; }
+                    double dd = ddot(pv_n, w);
+                    if (s < 0.0) s = 0.0;
+                    if (dd < 0.0) dd = 0.0;
+                    fst[(nverts - 1) * 3 + 0] = dc[0] * dd + sc[0] * s;
+                    fst[(nverts - 1) * 3 + 1] = dc[1] * dd + sc[1] * s;
+                    fst[(nverts - 1) * 3 + 2] = dc[2] * dd + sc[2] * s;
+                }
+
+                if (is_light) {                                              // main.cpp:132-135
+                    double c0 = m->ref[0], c1 = m->ref[1], c2 = m->ref[2];
+                    for (int k = nverts - 1; k >= 0; k--) {
+                        c0 = c0 * fst[k * 3 + 0]; c1 = c1 * fst[k * 3 + 1]; c2 = c2 * fst[k * 3 + 2];
+                    }
+                    end_path(c0, c1, c2);
+                } else if (dead_end) {
+                    for (int k = 0; k < kp.light_draws; k++) rng_next(rng);  // rand_point of the first light
+                    end_path(0.0, 0.0, 0.0);
+                } else if (nverts >= RT_MAXV) {
+                    atomicOr(&kp.ctrl[1], ERR_STACK);
+                    end_path(0.0, 0.0, 0.0);
+                } else {
+                    d3 fwd;
+                    int change = 1;
+                    double n2 = 1.0;
+                    bool reflect = false;
+                    const double rindex = m->rindex;
+                    if (__builtin_fabs(rindex - n_cur) < 0.0001) {           // leaving, main.cpp:158-161
+                        fwd = refraction_dir(d, normal, rindex, n_cur);
+                        change = 0;
+                    } else if (rindex == 0.0 || rng_next(rng) < 1073741823u) {   // main.cpp:164-167
+                        fwd = reflection_dir(d, normal, *m, rng, &kp.ctrl[1]);
+                        reflect = true;
+                    } else {                                                 // main.cpp:168-171
+                        fwd = refraction_dir(d, normal, rindex, n_cur);
+                        n2 = rindex;
+                    }
+                    pv_p = h.p; pv_n = normal; pv_r = dneg(reflect_dir(d, normal)); pv_mat = mi; pv_reflect = reflect;
+                    nverts++;
+                    o = h.p; d = fwd; remaining -= change; n_cur = n2;
+                }
+            }
+        }
+    }
+
+    // ---- counters: wave sums, one 64-bit atomic each per wave
+    unsigned long long r = nrays, cn = ncand_total;
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
+    if (lane == 0 && r) {
+        atomicAdd((unsigned long long*)(kp.ctrl + 2), r);
+        atomicAdd((unsigned long long*)(kp.ctrl + 4), cn);
+    }
+}
+
+// fn: 0 sin, 1 cos, 2 acos, 3 pow, 4 x/y, 5 sqrt(x), 6 next RNG state of (uint64)x bits
+__global__ void selftest_math_kernel(int fn, int n, const double* x, const double* y, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (fn) {
+        case 0: r = rtm::sind(x[i]); break;
+        case 1: r = rtm::cosd(x[i]); break;
+        case 2: r = rtm::acosd(x[i]); break;
+        case 3: r = rtm::powd(x[i], y[i]); break;
+        case 4: r = x[i] / y[i]; break;
+        case 5: r = __builtin_sqrt(x[i]); break;
+        default: { unsigned s = (unsigned)__double_as_longlong(x[i]); rng_next(s); r = __longlong_as_double((long long)s); } break;
+    }
+    out[i] = r;
+}
+
+// broad-phase self-test: n independent (ray, record) pairs; flag[i] = 1 if the float test keeps the pair
+__global__ void selftest_broad_kernel(int n, const double* o, const double* d, const float4* rec, float cmax,
+                                      double tx, double ty, double tz, int* flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KParams kp;
+    kp.cmax = cmax; kp.T[0] = tx; kp.T[1] = ty; kp.T[2] = tz;
+    Broad b = broad_setup(dmk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dmk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), kp);
+    float hb, q;
+    float disc = broad_disc(rec[i], b, hb, q);
+    int f = 0;
+    if (disc >= 0.0f) f = (hb > b.behind_h && q > b.behind_c) ? 2 : 1;   // 2 = culled as "behind"
+    flag[i] = f;
+}
+
+}  // namespace
+
+// ======================================================================= host side
+struct rt_context {
+    int device = 0;
+    int cu_count = 0;
+    std::string err;
+    bool have_scene = false;
+    // frame parameters
+    int width = 0, height = 0, spp = 0, depth = 0, num_threads = 1;
+    double scale = 0, lens = 0, focal = 0;
+    unsigned frame_seed = 0;
+    int has_light = 0, light_draws = 0;
+    uint64_t n_spheres = 0, n_planes = 0, n_faces = 0, n_face_verts = 0;
+    // device scene
+    void* d_records = nullptr;
+    void* d_chunks = nullptr;
+    void* d_prims = nullptr;
+    void* d_verts = nullptr;
+    void* d_mats = nullptr;
+    int nchunks = 0;
+    int max_chunk_records = 0;
+    float cmax = 0;
+    double T[3] = {0, 0, 0};
+    unsigned* d_ctrl = nullptr;
+    unsigned long long* d_stream_rays = nullptr; int stream_cap = 0;
+    // scratch outputs of rt_render
+    double* d_rgb = nullptr; size_t d_rgb_bytes = 0;
+    int32_t* d_hits = nullptr; size_t d_hits_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool events_pending = false;
+    int last_streams = 0;
+    rt_timing timing{};
+    int block = 256;
+    int grid_mult = 0;     // workgroups per CU, 0 = ask the occupancy API
+    int chunk_records = 4096;
+};
+
+namespace {
+
+int fail(rt_context* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(h, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_scene(rt_context* h) {
+    hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats);
+    h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = nullptr;
+    h->have_scene = false;
+}
+
+// largest float <= x
+float round_down_f(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+template <int BLOCK>
+hipError_t launch_render(rt_context* h, const KParams& kp, hipStream_t st) {
+    auto kern = render_kernel<BLOCK>;
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = h->grid_mult;
+    if (per_cu <= 0) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+    }
+    unsigned grid = (unsigned)(h->cu_count * per_cu);
+    unsigned need = (kp.total_items + BLOCK - 1) / BLOCK;
+    if (need < grid) grid = need ? need : 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, kp);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(rt_handle* out, int device) {
+    if (!out) return RT_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RT_ERR_NO_DEVICE;
+    rt_context* h = new rt_context();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
+    h->cu_count = prop.multiProcessorCount;
+    if (hipMalloc((void**)&h->d_ctrl, 64) != hipSuccess) { delete h; return RT_ERR_HIP; }
+    hipEventCreate(&h->ev0);
+    hipEventCreate(&h->ev1);
+    if (const char* e = getenv("RT_BLOCK")) { int b = atoi(e); if (b == 256 || b == 512 || b == 1024) h->block = b; }
+    if (const char* e = getenv("RT_WG_PER_CU")) h->grid_mult = atoi(e);
+    if (const char* e = getenv("RT_CHUNK_RECORDS")) { int k = atoi(e); if (k >= 64 && k <= 9728) h->chunk_records = k / BROAD_UNROLL * BROAD_UNROLL; }
+    *out = h;
+    return RT_OK;
+}
+
+void rt_destroy(rt_handle h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    free_scene(h);
+    hipFree(h->d_ctrl); hipFree(h->d_rgb); hipFree(h->d_hits); hipFree(h->d_stream_rays);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    delete h;
+}
+
+const char* rt_last_error(rt_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int rt_rows_for_rank(int height, int tile_rows, int rank, int world) {
+    if (height < 0 || tile_rows < 1 || world < 1 || rank < 0 || rank >= world) return RT_ERR_ARG;
+    int rows = 0;
+    for (long k = rank; k * tile_rows < height; k += world) {
+        long r0 = k * tile_rows, r1 = r0 + tile_rows;
+        if (r1 > height) r1 = height;
+        rows += (int)(r1 - r0);
+    }
+    return rows;
+}
+
+int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double* prims, int n_mats,
+                    const double* mats, int n_verts, const double* verts) {
+    if (!h) return RT_ERR_ARG;
+    if (!params || n_prims < 0 || n_mats < 0 || n_verts < 0 || (n_prims && !prims) || (n_mats && !mats) || (n_verts && !verts))
+        return fail(h, RT_ERR_ARG, "rt_upload_scene: null table or negative count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipEvent_t t0, t1;
+    hipEventCreate(&t0); hipEventCreate(&t1);
+    hipEventRecord(t0, 0);
+    const int W = (int)params[RT_PA_WIDTH], H = (int)params[RT_PA_HEIGHT];
+    const int spp = (int)params[RT_PA_SPP], depth = (int)params[RT_PA_DEPTH];
+    if (W < 1 || H < 1 || spp < 1 || depth < 0) return fail(h, RT_ERR_ARG, "rt_upload_scene: width, height, paths_per_pixel must be >= 1, depth >= 0");
+    if (depth > RT_MAX_DEPTH) return fail(h, RT_ERR_SCENE, "rt_upload_scene: max_ray_depth exceeds RT_MAX_DEPTH");
+    if ((uint64_t)W * (uint64_t)H >= (1ull << 31)) return fail(h, RT_ERR_SCENE, "rt_upload_scene: more than 2^31 pixels");
+
+    // ---- materials
+    std::vector<MatD> md((size_t)n_mats > 0 ? n_mats : 1);
+    memset(md.data(), 0, md.size() * sizeof(MatD));
+    for (int i = 0; i < n_mats; i++) {
+        const double* m = mats + (size_t)i * RT_MT_STRIDE;
+        MatD& o = md[i];
+        for (int k = 0; k < 3; k++) {
+            o.ref[k] = m[RT_MT_REF + k]; o.diff[k] = m[RT_MT_DIFF + k]; o.spec[k] = m[RT_MT_SPEC + k];
+            o.rdiff[k] = m[RT_MT_RDIFF + k]; o.rspec[k] = m[RT_MT_RSPEC + k];
+        }
+        o.is_light = m[RT_MT_LIGHT] != 0.0;
+        // generators() < gloss*generators.max() (main.cpp:48) for an integer draw g: g < ceil(gloss*max);
+        // a NaN gloss never compares true.
+        double thr = m[RT_MT_GLOSS] * 2147483646.0;
+        unsigned it = 0;
+        if (thr > 0.0) {
+            if (thr >= 4294967295.0) it = 4294967295u;
+            else { it = (unsigned)thr; if ((double)it < thr) it++; }
+        }
+        o.gloss_thr = it;
+        o.sexp = m[RT_MT_SEXP];
+        o.rindex = m[RT_MT_RINDEX];
+    }
+
+    // ---- exact tables + bounding spheres (centre, radius; radius < 0 = unbounded)
+    std::vector<PrimD> pd((size_t)n_prims > 0 ? n_prims : 1);
+    memset(pd.data(), 0, pd.size() * sizeof(PrimD));
+    std::vector<double> bc((size_t)n_prims * 3 + 3, 0.0), br((size_t)n_prims + 1, -1.0);
+    h->n_spheres = h->n_planes = h->n_faces = h->n_face_verts = 0;
+    int first_light = -1;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n_prims; i++) {
+        const double* p = prims + (size_t)i * RT_PR_STRIDE;
+        const int kind = (int)p[RT_PR_KIND];
+        if (kind < 0 || kind > 2) return fail(h, RT_ERR_ARG, "rt_upload_scene: bad primitive kind");
+        const int m0 = (int)p[RT_PR_MAT0], m1 = (int)p[RT_PR_MAT1];
+        if (m0 < 0 || m0 >= n_mats || m1 < 0 || m1 >= n_mats) return fail(h, RT_ERR_ARG, "rt_upload_scene: material index out of range");
+        PrimD& q = pd[i];
+        q.kind = kind; q.mat0 = m0; q.mat1 = m1;
+        for (int k = 0; k < 3; k++) { q.a[k] = p[RT_PR_A + k]; q.n[k] = p[RT_PR_N + k]; }
+        q.radius = p[RT_PR_RADIUS];
+        if (p[RT_PR_LIGHT] != 0.0 && first_light < 0) first_light = i;
+        bool bounded = false;
+        if (kind == RT_KIND_SPHERE) {
+            h->n_spheres++;
+            if (std::isfinite(q.a[0]) && std::isfinite(q.a[1]) && std::isfinite(q.a[2]) && std::isfinite(q.radius)) {
+                for (int k = 0; k < 3; k++) bc[(size_t)i * 3 + k] = q.a[k];
+                br[i] = fabs(q.radius);
+                bounded = true;
+            }
+        } else if (kind == RT_KIND_PLANE) {
+            h->n_planes++;
+        } else {
+            const int nv = (int)p[RT_PR_VCNT], off = (int)p[RT_PR_VOFF];
+            if (nv < 1 || nv > RT_MAX_FACE_VERTS || off < 0 || off + nv > n_verts)
+                return fail(h, RT_ERR_SCENE, "rt_upload_scene: face vertex range invalid or more than RT_MAX_FACE_VERTS vertices");
+            q.voff = off; q.vcnt = nv;
+            h->n_faces++;
+            h->n_face_verts += (uint64_t)nv;
+            // The reference accepts a point of the plane (verts[0], normal) iff, for every i, it is not on the
+            // other side of edge (v_i, v_i+1) than v_i+2.  For a planar convex polygon whose plane is the one
+            // the normal describes that region is the polygon, which lies inside the sphere around its
+            // vertices.  Anything else keeps an unbounded sphere (always a candidate).
+            const double* v = verts + (size_t)off * 3;
+            bool ok = nv >= 3;
+            double c[3] = {0, 0, 0};
+            for (int k = 0; k < nv && ok; k++) for (int a = 0; a < 3; a++) { if (!std::isfinite(v[3 * k + a])) ok = false; c[a] += v[3 * k + a] / nv; }
+            double R = 0, ext = 0;
+            for (int k = 0; k < nv && ok; k++) {
+                double dd = 0;
+                for (int a = 0; a < 3; a++) dd += (v[3 * k + a] - c[a]) * (v[3 * k + a] - c[a]);
+                if (sqrt(dd) > R) R = sqrt(dd);
+            }
+            ext = R > 0 ? R : 1.0;
+            for (int k = 0; k < nv && ok; k++) {          // planarity w.r.t. the given normal
+                double dist = 0;
+                for (int a = 0; a < 3; a++) dist += (v[3 * k + a] - v[a]) * q.n[a];
+                if (!(fabs(dist) <= 1e-9 * ext)) ok = false;
+            }
+            for (int k = 0; k < nv && ok; k++) {          // convexity: all vertices on one side of every edge
+                const double* a0 = v + 3 * k; const double* a1 = v + 3 * ((k + 1) % nv);
+                double e[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
+                double s[3] = {e[1] * q.n[2] - e[2] * q.n[1], e[2] * q.n[0] - e[0] * q.n[2], e[0] * q.n[1] - e[1] * q.n[0]};
+                int sign = 0;
+                for (int j = 0; j < nv && ok; j++) {
+                    const double* b = v + 3 * j;
+                    double t = (b[0] - a0[0]) * s[0] + (b[1] - a0[1]) * s[1] + (b[2] - a0[2]) * s[2];
+                    if (fabs(t) <= 1e-9 * ext * ext) continue;
+                    int sg = t > 0 ? 1 : -1;
+                    if (sign == 0) sign = sg; else if (sg != sign) ok = false;
+                }
+            }
+            if (ok) {
+                for (int k = 0; k < 3; k++) bc[(size_t)i * 3 + k] = c[k];
+                br[i] = R * (1.0 + 1e-6) + 1e-6 * ext;
+                bounded = true;
+            }
+        }
+        if (bounded) for (int k = 0; k < 3; k++) {
+            double a = bc[(size_t)i * 3 + k];
+            if (a - br[i] < lo[k]) lo[k] = a - br[i];
+            if (a + br[i] > hi[k]) hi[k] = a + br[i];
+        }
+    }
+    double T[3] = {0, 0, 0};
+    if (lo[0] <= hi[0]) for (int k = 0; k < 3; k++) T[k] = 0.5 * (lo[k] + hi[k]);
+    double cmax = 0;
+
+    // ---- broad-phase records in file order, chunked to the LDS window, padded with NaN records
+    std::vector<float> rec;
+    std::vector<ChunkDesc> chunks;
+    const int cap = h->chunk_records;
+    for (int i = 0; i < n_prims; i++) {
+        if (i % cap == 0) {
+            ChunkDesc c; c.gofs = (int)(rec.size() / 4); c.count = 0; c.first_index = i; c.pad = 0;
+            chunks.push_back(c);
+        }
+        float r4[4];
+        if (br[i] < 0) {
+            r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = -INFINITY;       // unbounded: q = -inf, always kept, never "behind"
+        } else {
+            float cf[3];
+            double c2 = 0, cn = 0;
+            for (int k = 0; k < 3; k++) {
+                cf[k] = (float)(bc[(size_t)i * 3 + k] - T[k]);
+                c2 += (double)cf[k] * cf[k];
+                cn += (bc[(size_t)i * 3 + k] - T[k]) * (bc[(size_t)i * 3 + k] - T[k]);
+            }
+            // radius inflated for the rounding of the centre (<= u |c| per component) and a relative 1e-6
+            double Rr = br[i] * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
+            r4[0] = cf[0]; r4[1] = cf[1]; r4[2] = cf[2];
+            r4[3] = round_down_f(c2 - Rr * Rr);
+            if (sqrt(cn) + Rr > cmax) cmax = sqrt(cn) + Rr;
+        }
+        rec.insert(rec.end(), r4, r4 + 4);
+        chunks.back().count++;
+    }
+    // pad every chunk to the unroll width inside the record stream; NaN records are never kept
+    {
+        std::vector<float> padded;
+        int src = 0;
+        for (auto& c : chunks) {
+            c.gofs = (int)(padded.size() / 4);
+            padded.insert(padded.end(), rec.begin() + (size_t)src * 4, rec.begin() + (size_t)(src + c.count) * 4);
+            src += c.count;
+            while (c.count % BROAD_UNROLL) { for (int k = 0; k < 4; k++) padded.push_back(NAN); c.count++; }
+        }
+        rec.swap(padded);
+    }
+    if (chunks.empty()) { ChunkDesc c; c.gofs = 0; c.count = 0; c.first_index = 0; c.pad = 0; chunks.push_back(c); }
+    if (rec.empty()) rec.assign(4, NAN);
+    int maxrec = BROAD_UNROLL;
+    for (auto& c : chunks) if (c.count > maxrec) maxrec = c.count;
+    std::vector<double> vd((size_t)(n_verts > 0 ? n_verts : 1) * 3, 0.0);
+    if (n_verts) memcpy(vd.data(), verts, (size_t)n_verts * 3 * sizeof(double));
+
+    free_scene(h);
+    HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
+    HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));
+    HIP_TRY(h, hipMalloc(&h->d_verts, vd.size() * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_mats, md.size() * sizeof(MatD)));
+    HIP_TRY(h, hipMemcpy(h->d_records, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_prims, pd.data(), pd.size() * sizeof(PrimD), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_verts, vd.data(), vd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_mats, md.data(), md.size() * sizeof(MatD), hipMemcpyHostToDevice));
+
+    h->width = W; h->height = H; h->spp = spp; h->depth = depth;
+    h->num_threads = (int)params[RT_PA_THREADS] > 0 ? (int)params[RT_PA_THREADS] : 1;
+    h->scale = params[RT_PA_SCALE]; h->lens = params[RT_PA_LENS]; h->focal = params[RT_PA_FOCAL];
+    h->frame_seed = (unsigned)params[RT_PA_SEED];
+    h->has_light = first_light >= 0;
+    h->light_draws = 0;
+    if (first_light >= 0) {
+        int k = (int)prims[(size_t)first_light * RT_PR_STRIDE + RT_PR_KIND];
+        h->light_draws = (k == RT_KIND_PLANE) ? 0 : 2;   // rand_point, geometry.cpp:120,145-150,175-179
+    }
+    h->nchunks = (int)chunks.size();
+    h->max_chunk_records = maxrec;
+    h->cmax = (float)(cmax * (1.0 + 1e-6)) ;
+    for (int k = 0; k < 3; k++) h->T[k] = T[k];
+    h->have_scene = true;
+    hipEventRecord(t1, 0);
+    hipEventSynchronize(t1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, t0, t1);
+    h->timing.upload_ms = ms;
+    hipEventDestroy(t0); hipEventDestroy(t1);
+    return RT_OK;
+}
+
+static int render_common(rt_handle h, int stream_mode, int tile_rows, int rank, int world, double* d_rgb,
+                         int32_t* d_hit_ids, void* stream) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    KParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
+    kp.scale = h->scale; kp.lens = h->lens; kp.focal = h->focal; kp.frame_seed = h->frame_seed;
+    kp.has_light = h->has_light; kp.light_draws = h->light_draws;
+    kp.tile_rows = tile_rows; kp.rank = rank; kp.world = world;
+    kp.stream_mode = stream_mode;
+    if (stream_mode) {
+        kp.n_streams = h->num_threads;
+        kp.total_items = (unsigned)h->num_threads;
+        if (h->stream_cap < h->num_threads) {
+            hipFree(h->d_stream_rays); h->d_stream_rays = nullptr; h->stream_cap = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->d_stream_rays, (size_t)h->num_threads * 8));
+            h->stream_cap = h->num_threads;
+        }
+        HIP_TRY(h, hipMemsetAsync(h->d_stream_rays, 0, (size_t)h->num_threads * 8, st));
+        kp.stream_rays = h->d_stream_rays;
+    } else {
+        const int rows = rt_rows_for_rank(h->height, tile_rows, rank, world);
+        kp.total_items = (unsigned)((uint64_t)rows * (uint64_t)h->width);
+    }
+    h->last_streams = stream_mode ? h->num_threads : 0;
+    kp.nchunks = h->nchunks;
+    kp.cmax = h->cmax;
+    for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
+    kp.records = (const float4*)h->d_records;
+    kp.chunks = (const ChunkDesc*)h->d_chunks;
+    kp.prims = (const PrimD*)h->d_prims;
+    kp.verts = (const double*)h->d_verts;
+    kp.mats = (const MatD*)h->d_mats;
+    kp.rgb = d_rgb; kp.hit_ids = d_hit_ids; kp.ctrl = h->d_ctrl;
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 64, st));
+    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (kp.total_items > 0) {
+        hipError_t e;
+        if (h->block == 1024) e = launch_render<1024>(h, kp, st);
+        else if (h->block == 512) e = launch_render<512>(h, kp, st);
+        else e = launch_render<256>(h, kp, st);
+        if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("render kernel launch: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    h->events_pending = true;
+    return RT_OK;
+}
+
+int rt_render_rows_device(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render_rows_device: no scene uploaded");
+    if (!d_rgb || tile_rows < 1 || world < 1 || rank < 0 || rank >= world) return fail(h, RT_ERR_ARG, "rt_render_rows_device: bad argument");
+    return render_common(h, 0, tile_rows, rank, world, d_rgb, d_hit_ids, stream);
+}
+
+int rt_render_streams_device(rt_handle h, double* d_rgb, int32_t* d_hit_ids, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render_streams_device: no scene uploaded");
+    if (!d_rgb) return fail(h, RT_ERR_ARG, "rt_render_streams_device: bad argument");
+    return render_common(h, 1, 1, 0, 1, d_rgb, d_hit_ids, stream);
+}
+
+int rt_finish(rt_handle h, uint64_t* rays) {
+    if (!h) return RT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->events_pending) return fail(h, RT_ERR_ARG, "rt_finish: no render in flight");
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    h->events_pending = false;
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    unsigned ctrl[6];
+    HIP_TRY(h, hipMemcpy(ctrl, h->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
+    uint64_t r = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
+    h->timing.kernel_ms = ms;
+    h->timing.rays = r;
+    h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
+    h->timing.sphere_tests = r * h->n_spheres;
+    h->timing.plane_tests = r * h->n_planes;
+    h->timing.face_tests = r * h->n_faces;
+    h->timing.face_vert_tests = r * h->n_face_verts;
+    if (rays) *rays = r;
+    if (ctrl[1] & ERR_REJECT_GUARD) return fail(h, RT_ERR_GUARD, "render: the glossy rejection loop did not accept within its guard (a glossy surface hit from behind: the reference never terminates on this scene)");
+    if (ctrl[1] & ERR_STACK) return fail(h, RT_ERR_GUARD, "render: bounce stack overflow (path longer than 2*max_ray_depth+2 vertices: no emitter in the scene?)");
+    return RT_OK;
+}
+
+int rt_stream_rays(rt_handle h, uint64_t* out, int n) {
+    if (!h || !out || n < 0) return RT_ERR_ARG;
+    if (h->events_pending) return fail(h, RT_ERR_ARG, "rt_stream_rays: call rt_finish first");
+    if (n > h->last_streams) return fail(h, RT_ERR_ARG, "rt_stream_rays: the last render had fewer streams");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (n) HIP_TRY(h, hipMemcpy(out, h->d_stream_rays, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+static int render_host(rt_handle h, int stream_mode, double* rgb, uint64_t* rays, int32_t* hit_ids) {
+    if (!h) return RT_ERR_ARG;
+    if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+    if (!rgb) return fail(h, RT_ERR_ARG, "rt_render: rgb is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipEvent_t t0, t1;
+    hipEventCreate(&t0); hipEventCreate(&t1);
+    hipEventRecord(t0, 0);
+    const size_t npx = (size_t)h->width * h->height;
+    const size_t rb = npx * 3 * sizeof(double), hb = npx * h->spp * sizeof(int32_t);
+    if (h->d_rgb_bytes < rb) { hipFree(h->d_rgb); h->d_rgb = nullptr; h->d_rgb_bytes = 0; HIP_TRY(h, hipMalloc((void**)&h->d_rgb, rb)); h->d_rgb_bytes = rb; }
+    if (hit_ids && h->d_hits_bytes < hb) { hipFree(h->d_hits); h->d_hits = nullptr; h->d_hits_bytes = 0; HIP_TRY(h, hipMalloc((void**)&h->d_hits, hb)); h->d_hits_bytes = hb; }
+    int rc = render_common(h, stream_mode, h->height, 0, 1, h->d_rgb, hit_ids ? h->d_hits : nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    rc = rt_finish(h, rays);
+    HIP_TRY(h, hipMemcpy(rgb, h->d_rgb, rb, hipMemcpyDeviceToHost));
+    if (hit_ids) HIP_TRY(h, hipMemcpy(hit_ids, h->d_hits, hb, hipMemcpyDeviceToHost));
+    hipEventRecord(t1, 0);
+    hipEventSynchronize(t1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, t0, t1);
+    h->timing.total_ms = ms;
+    hipEventDestroy(t0); hipEventDestroy(t1);
+    return rc;
+}
+
+int rt_render(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { return render_host(h, 0, rgb, rays, hit_ids); }
+
+int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { return render_host(h, 1, rgb, rays, hit_ids); }
+
+int rt_last_timing(rt_handle h, rt_timing* out) {
+    if (!h || !out) return RT_ERR_ARG;
+    *out = h->timing;
+    return RT_OK;
+}
+
+int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* y, double* out) {
+    if (!h || n < 0 || !x || !out || fn < 0 || fn > 6) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    size_t b = (size_t)n * sizeof(double);
+    HIP_TRY(h, hipMalloc((void**)&dx, b));
+    HIP_TRY(h, hipMalloc((void**)&dy, b));
+    HIP_TRY(h, hipMalloc((void**)&dout, b));
+    HIP_TRY(h, hipMemcpy(dx, x, b, hipMemcpyHostToDevice));
+    if (y) HIP_TRY(h, hipMemcpy(dy, y, b, hipMemcpyHostToDevice));
+    else HIP_TRY(h, hipMemset(dy, 0, b));
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy, dout);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpy(out, dout, b, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return RT_OK;
+}
+
+int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* dirs, const double* centres,
+                      const double* radii, int32_t* flags) {
+    if (!h || n < 0 || !origins || !dirs || !centres || !radii || !flags) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // same record construction as rt_upload_scene, with T = 0 and cmax over the batch
+    std::vector<float> rec((size_t)n * 4);
+    double cmax = 0;
+    for (int i = 0; i < n; i++) {
+        double c2 = 0, cn = 0;
+        float cf[3];
+        for (int k = 0; k < 3; k++) { cf[k] = (float)centres[3 * (size_t)i + k]; c2 += (double)cf[k] * cf[k]; cn += centres[3 * (size_t)i + k] * centres[3 * (size_t)i + k]; }
+        double Rr = fabs(radii[i]) * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
+        rec[4 * (size_t)i] = cf[0]; rec[4 * (size_t)i + 1] = cf[1]; rec[4 * (size_t)i + 2] = cf[2];
+        rec[4 * (size_t)i + 3] = round_down_f(c2 - Rr * Rr);
+        if (sqrt(cn) + Rr > cmax) cmax = sqrt(cn) + Rr;
+    }
+    double *dO = nullptr, *dD = nullptr; float4* dR = nullptr; int* dF = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&dO, (size_t)n * 24));
+    HIP_TRY(h, hipMalloc((void**)&dD, (size_t)n * 24));
+    HIP_TRY(h, hipMalloc((void**)&dR, (size_t)n * 16));
+    HIP_TRY(h, hipMalloc((void**)&dF, (size_t)n * 4));
+    HIP_TRY(h, hipMemcpy(dO, origins, (size_t)n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dD, dirs, (size_t)n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dR, rec.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_broad_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, dO, dD, dR,
+                       (float)(cmax * (1.0 + 1e-6)), 0.0, 0.0, 0.0, dF);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpy(flags, dF, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(dO); hipFree(dD); hipFree(dR); hipFree(dF);
+    return RT_OK;
+}
+
+}  // extern "C"

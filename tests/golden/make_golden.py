@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures of tests/golden/ from the compiled, unmodified
+reference (oracle/_ref/ref_harness, built by `make -C oracle ref` from the
+sources under /root/reference/src).  Run in the build container only; the
+fixtures it writes are data (scene streams, pixel arrays, hashes, counters).
+
+    python tests/golden/make_golden.py
+
+Outputs:
+  golden.json               per case: thread count, blurs, per-thread ray counters,
+                            sha256 of the un-exposed Color array (float64 bytes) and
+                            of the packed 8-bit image (uint8 RGB bytes), mean RGB
+  scene_json_t4_b3.npz      full 8-bit image of the reference's own scene.json run
+  small_room.scene.json / small_mixed.scene.json   synthetic scene streams
+  small_room_t8_b1.npz / small_mixed_t8_b0.npz     their full 8-bit images
+  rng_kat.json              libstdc++ default_random_engine known answers
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import pyoracle as po  # noqa: E402
+from raytracer_amd import synth  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def case(name, text, T, blurs, save_pixels=None):
+    ref = po.run_reference(text, num_threads=T, num_blurs=blurs)
+    rgb8 = po.unpack_rgb(ref["img"])
+    entry = {"scene": name, "threads": T, "blurs": blurs, "rays": [int(x) for x in ref["rays"]],
+             "sha256_colors_f64": sha(ref["rgb"]), "sha256_rgb8": sha(rgb8),
+             "mean_rgb8": [float(x) for x in rgb8.reshape(-1, 3).mean(0)],
+             "width": int(rgb8.shape[1]), "height": int(rgb8.shape[0])}
+    if save_pixels:
+        np.savez_compressed(os.path.join(HERE, save_pixels), rgb8=rgb8)
+        entry["pixels"] = save_pixels
+    print(entry["scene"], T, blurs, sum(entry["rays"]), entry["sha256_rgb8"][:16])
+    return entry
+
+
+def rng_kat():
+    src = r"""
+#include <random>
+#include <cstdio>
+int main(){ std::default_random_engine g; std::default_random_engine h; h.seed(0);
+  printf("{\"first5\":["); for(int i=0;i<5;i++) printf("%s%lu", i?",":"", (unsigned long)g());
+  for(int i=5;i<9999;i++) g(); printf("],\"v10000\":%lu,\"seed0_first\":%lu,\"min\":%lu,\"max\":%lu}\n",
+  (unsigned long)g(), (unsigned long)h(), (unsigned long)g.min(), (unsigned long)g.max()); }
+"""
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "k.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-O1", "-o", os.path.join(td, "k"), os.path.join(td, "k.cpp")])
+        return json.loads(subprocess.check_output([os.path.join(td, "k")]).decode())
+
+
+def main():
+    if not po.have_reference():
+        sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` first")
+    out = []
+    text = open("/root/reference/scene.json").read()
+    for T, b in ((1, 0), (4, 0), (4, 3), (8, 0), (8, 3), (400, 0)):
+        out.append(case("scene.json", text, T, b, "scene_json_t4_b3.npz" if (T, b) == (4, 3) else None))
+
+    # closed room, 6x4x4 lattice, 20 % glass spheres: reflection, refraction, checker floor
+    synth.CONFIGS["_g1"] = dict(width=160, height=90, lattice=(6, 4, 4), count=None, emitters=2, planes=0, depth=4,
+                                spp=4, lens=1.0, glass=0.2, quads=0.0)
+    t1, _ = synth.make("_g1", num_threads=8, num_blurs=1)
+    open(os.path.join(HERE, "small_room.scene.json"), "w").write(t1)
+    out.append(case("small_room.scene.json", t1, 8, 1, "small_room_t8_b1.npz"))
+    out.append(case("small_room.scene.json", t1, 3, 0))
+
+    # mixed primitives: spheres, free-floating diffuse quads, planes behind the walls, 8 emitters
+    synth.CONFIGS["_g2"] = dict(width=96, height=54, lattice=(8, 4, 8), count=200, emitters=8, planes=7, depth=4,
+                                spp=4, lens=1.0, glass=0.05, quads=0.25)
+    t2, _ = synth.make("_g2", num_threads=8, num_blurs=0)
+    open(os.path.join(HERE, "small_mixed.scene.json"), "w").write(t2)
+    out.append(case("small_mixed.scene.json", t2, 8, 0, "small_mixed_t8_b0.npz"))
+
+    json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+    json.dump(rng_kat(), open(os.path.join(HERE, "rng_kat.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
