@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One step = one frame of the workload: every rank renders its cyclic row tiles of the SAME
+frame (scene tables already resident in HBM), the tiles are gathered to rank 0 (RCCL) and
+de-interleaved there.  The frame is fixed, so scaling over N is strong scaling.
+
+Prints ONE JSON line on rank 0: Mrays/s (whole job), ms per frame, the FP32-VALU roofline
+figure of the render kernel (algorithmic FLOP of the closest-hit scan / kernel time, HIP
+events on the launch stream) and, at N = 1, the CPU baseline: the reference's own binary
+(oracle/_ref, kind "reference") or the oracle port timed on the host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracer_amd import api, synth  # noqa: E402
+from raytracer_amd.dist import FrameGatherer, sum_over_ranks  # noqa: E402
+
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32, FMA = 2 FLOP
+
+
+def algorithmic_flops(t, sc):
+    """FLOP of the closest-hit scan as the reference defines the work: every ray is tested against
+    every solid; 19 per sphere, 12 per plane, 18 + 7*verts per face (FMA = 2)."""
+    return 19 * t["sphere_tests"] + 12 * t["plane_tests"] + 18 * t["face_tests"] + 7 * t["face_vert_tests"]
+
+
+def cpu_baseline(workload, cores):
+    """Time the CPU path on a bounded sample: the same scene at 1/4 linear resolution (identical
+    framing: scale = width/40).  Prefers the compiled reference binary; falls back to the oracle port."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cfg = synth.CONFIGS[workload]
+    w = max(64, cfg["width"] // 4)
+    text, sc = synth.make(workload, width=w, num_threads=cores)
+    sample = f"{workload} at {sc.width}x{sc.height} (1/4 linear resolution, same framing), {cores} threads, render+expose as main.cpp:305-315 times it"
+    try:
+        if po.have_reference():
+            r = po.run_reference(text, num_threads=cores, num_blurs=0, timeout=900)
+            rays = int(r["rays"].sum())
+            return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                    "sample": sample, "seconds": r["seconds"], "rays": rays}
+    except Exception as e:  # the binary may not run on this box (missing shared library)
+        sys.stderr.write(f"bench: reference binary not usable here ({e}); timing the oracle port\n")
+    t0 = time.time()
+    o = po.render(sc, policy=po.POLICY_REF, rng_mode=po.RNG_STREAM)
+    po.expose(o["rgb"], 1.0, 0, workers=cores)
+    secs = time.time() - t0
+    rays = int(o["rays"].sum())
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds": secs, "rays": rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--width", type=int, default=None, help="override the frame width (height follows 16:9)")
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE\n")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    _, sc = synth.make(args.workload, width=args.width)
+    ren = api.Renderer(local_rank)
+    ren.upload(sc)
+    H, W = sc.height, sc.width
+    gat = FrameGatherer(H, W, 3, args.tile_rows, rank, world, device)
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        ren.render_rows_device(gat.local.data_ptr(), args.tile_rows, rank, world, stream=stream.cuda_stream)
+        return gat.gather()
+
+    for _ in range(args.warmup):
+        step()
+        ren.finish()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        ren.render_rows_device(gat.local.data_ptr(), args.tile_rows, rank, world, stream=stream.cuda_stream)
+        ev[i][1].record(stream)
+        frame = gat.gather()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    rays_local = ren.finish()                     # counters of the last frame; every step renders the same frame
+    tm = ren.timing()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+    rays_frame = sum_over_ranks(rays_local, device, world)
+    flops_local = algorithmic_flops(tm, sc)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = rays_frame / (ms_per_step * 1e-3) / 1e6
+        achieved = flops_local / (kernel_ms * 1e-3) / 1e12
+        cnt = sc.counts()
+        out = {
+            "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 broad phase + f64 exact phase", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
+                                   f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
+                       "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
+                       "partition": f"cyclic row tiles over {world} GPU(s), gather to rank 0"},
+            "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": kernel_ms, "rays_this_gpu": rays_local,
+                         "candidates_per_ray": tm["candidates"] / max(1, tm["rays"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(args.workload, cores)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
