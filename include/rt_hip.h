@@ -87,7 +87,9 @@ enum {
 
 typedef struct {
     double upload_ms;      /* last rt_upload_scene: table flattening + H2D              */
-    double kernel_ms;      /* last render: device time of the render kernel (HIP events)*/
+    double kernel_ms;      /* last render: device time of all its kernels (HIP events)  */
+    double broad_ms;       /* last render: sum over its broad_kernel launches, measured  */
+                           /* only while RT_OPT_TIMING_DETAIL is on (else 0)             */
     double total_ms;       /* last rt_render: kernel + D2H of the outputs               */
     uint64_t rays;         /* last render: ray segments traced (reference: num_rays)    */
     uint64_t candidates;   /* last render: (ray, solid) pairs the FP32 broad phase kept */
@@ -98,12 +100,28 @@ typedef struct {
     uint64_t face_vert_tests;
 } rt_timing;
 
+/* options for rt_set_option */
+enum {
+    RT_OPT_MODE = 0,           /* RT_MODE_PIPELINE (default) or RT_MODE_SINGLE_KERNEL           */
+    RT_OPT_TIMING_DETAIL = 1,  /* 1: bracket every broad_kernel launch with HIP events          */
+    RT_OPT_BLOCK = 2,          /* workgroup size of the single-kernel renderer: 256/512/1024    */
+    RT_OPT_BROAD_BLOCK = 3,    /* workgroup size of broad_kernel: 256/512/1024                  */
+    RT_OPT_WG_PER_CU = 4,      /* persistent workgroups per CU, 0 = occupancy query             */
+    RT_OPT_CHUNK_RECORDS = 5,  /* LDS window in 16-byte records (next rt_upload_scene)          */
+    RT_OPT_MAX_SLOTS = 6       /* pixels whose path state is kept at once (memory cap)          */
+};
+enum { RT_MODE_PIPELINE = 0, RT_MODE_SINGLE_KERNEL = 1 };
+
 /* Create a context on HIP device `device` (index as HIP enumerates it).
  * Replaces: the allocation block of main(), main.cpp:300-303. */
 int rt_create(rt_handle* out, int device);
 
 /* Free device buffers and the context.  Replaces main.cpp:328-331. */
 void rt_destroy(rt_handle h);
+
+/* Tuning and instrumentation switches (RT_OPT_*); none of them changes a result bit.
+ * No counterpart in the reference. */
+int rt_set_option(rt_handle h, int key, int value);
 
 /* Copy the scene into device tables (float structure-of-arrays, file order kept).
  * params: RT_PA_COUNT doubles; prims: n_prims*RT_PR_STRIDE; mats: n_mats*RT_MT_STRIDE;

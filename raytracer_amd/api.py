@@ -19,10 +19,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librt_hip.so")
 
 RT_OK = 0
+# rt_set_option keys / values (include/rt_hip.h)
+OPT_MODE, OPT_TIMING_DETAIL, OPT_BLOCK, OPT_BROAD_BLOCK, OPT_WG_PER_CU, OPT_CHUNK_RECORDS, OPT_MAX_SLOTS = range(7)
+MODE_PIPELINE, MODE_SINGLE_KERNEL = 0, 1
 STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE", -4: "RT_ERR_SCENE",
           -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}
 
-EXPORTS = ("rt_create", "rt_destroy", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
+EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
 
@@ -34,7 +37,7 @@ class RtError(RuntimeError):
 
 
 class RtTiming(C.Structure):
-    _fields_ = [("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+    _fields_ = [("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("broad_ms", C.c_double), ("total_ms", C.c_double),
                 ("rays", C.c_uint64), ("candidates", C.c_uint64), ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
                 ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64)]
 
@@ -56,6 +59,8 @@ def load_library(path: str = LIB_PATH):
     l.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     l.rt_destroy.restype = None
     l.rt_destroy.argtypes = [C.c_void_p]
+    l.rt_set_option.restype = C.c_int
+    l.rt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     l.rt_upload_scene.restype = C.c_int
     l.rt_upload_scene.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
     l.rt_rows_for_rank.restype = C.c_int
@@ -116,6 +121,9 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key: int, value: int):
+        self._check(self.lib.rt_set_option(self.h, int(key), int(value)))
 
     def upload(self, sc: S.Scene):
         params = sc.params()

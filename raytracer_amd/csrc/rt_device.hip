@@ -88,6 +88,8 @@ struct KParams {
     int stream_mode, n_streams;
     unsigned total_items;
     int nchunks;
+    int n_prims;
+    int max_verts;           // bounce-stack entries available per path (<= RT_MAXV)
     float cmax;              // max |C - T| + R over finite bounding spheres
     double T[3];             // translation applied before rounding coordinates to float
     const float4* records;
@@ -281,135 +283,249 @@ DEV int plane_material(const PrimD& pi, d3 p) {
 }
 
 // ---- broad phase ---------------------------------------------------------------------------
-// Per-ray constants of the conservative float test.  With o, c relative to the translation T
-// and rounded to float, d rounded to float:
-//     hb  = d.(o - c)            = od - d.c
-//     oo  = |o - c|^2 - R^2      = o2 + (|c|^2 - R^2) - 2 o.c  = o2 + q
-//     the exact discriminant  hb^2 - oo >= 0  implies   hb~^2 + k1 |hb~| + K - q~ >= 0
-// where hb~, q~ are the float evaluations, k1 = 2 Eh, K = Eh^2 + E0 - o2 (rounded up) and
-//     Eh = 14 u (|o| + cmax)       bounds |hb~ - hb|   (input rounding + 4 roundings, doubled)
-//     E0 = 24 u (|o| + cmax)^2     bounds the error of o2 + q~ and of the last three operations.
-struct Broad {
-    float dx, dy, dz;      // -d
-    float mx, my, mz;      // -2 o
-    float od;              // d.o
-    float k1, K;
-    float behind_h, behind_c;   // sphere wholly behind the origin iff hb~ > behind_h and q~ > behind_c
+// Conservative float test of a ray against a bounding sphere (centre c, radius R), all
+// coordinates relative to the translation T and rounded to float.  With
+//     hb = d.(o - c) = d.o - d.c            oo = |o - c|^2 - R^2 = |o|^2 + (|c|^2 - R^2) - 2 o.c
+// the exact discriminant is hb^2 - oo.  The kernel evaluates, in 8 VALU instructions per record,
+//     hb' = od' - d'.c        (d' = d sqrt(1+delta), od' = d'.o: three fma)
+//     nq  = (R^2 - |c|^2) + 2 o.c            (three fma, the record carries R^2 - |c|^2)
+//     s   = hb'^2 + nq                        (one fma)          keep iff  s >= thr  (one compare)
+// with thr = |o|^2 - E0 - Eh^2 (1 + 1/delta).  If the float evaluation of hb is off by at most Eh
+// and that of oo by at most E0, then  hb^2 <= (|hb~| + Eh)^2 <= hb~^2 (1+delta) + Eh^2 (1+1/delta)
+// and  oo >= oo~ - E0, so a non-negative exact discriminant implies s >= thr: no primitive the
+// exact test could accept is ever dropped.  Bounds (S = |o| + cmax, u = 2^-24), with a factor 2 of
+// slack over the term-by-term count:  Eh = 14 u S,  E0 = 24 u S^2.
+// A kept sphere is still dropped if it lies wholly behind the origin: hb~ > Eh and oo~ > E0.
+constexpr float BROAD_DELTA = 1.9e-6f;         // used in thr; the applied scale 1.000001^2 - 1 is larger
+constexpr float BROAD_SCALE = 1.000001f;
+
+struct RayRec {
+    float4 a;   // -d' (xyz), od'
+    float4 b;   // 2 o (xyz), thr
+    float4 c;   // behind thresholds: hb' > c.x and nq < c.y ; zw unused
 };
 
-DEV Broad broad_setup(d3 o, d3 d, const KParams& kp) {
-    Broad b;
-    const float ox = (float)(o.x - kp.T[0]), oy = (float)(o.y - kp.T[1]), oz = (float)(o.z - kp.T[2]);
-    const float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax) {
+    RayRec r;
+    const float ox = (float)(o.x - T[0]), oy = (float)(o.y - T[1]), oz = (float)(o.z - T[2]);
+    const float fx = (float)d.x * BROAD_SCALE, fy = (float)d.y * BROAD_SCALE, fz = (float)d.z * BROAD_SCALE;
     const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
     const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
-    const float S = __builtin_sqrtf((float)o2) * 1.0001f + kp.cmax;
+    const float S = __builtin_sqrtf((float)o2) * 1.0001f + cmax;
     const float Eh = 14.0f * F32_U * S;
     const float E0 = 24.0f * F32_U * S * S;
-    b.dx = -fx; b.dy = -fy; b.dz = -fz;
-    b.mx = -2.0f * ox; b.my = -2.0f * oy; b.mz = -2.0f * oz;
-    b.od = (float)od;
-    b.k1 = 2.0f * Eh * 1.0001f;
-    const double Kd = (double)Eh * Eh + (double)E0 - o2;
-    b.K = (float)Kd + __builtin_fabsf((float)Kd) * (4.0f * F32_U);
-    // wholly behind: true hb >= hb~ - Eh > 0 and true oo >= o2 + q~ - E0 > 0  (origin outside, centre behind)
-    b.behind_h = Eh;
-    b.behind_c = (float)((double)E0 - o2) + __builtin_fabsf((float)o2) * (4.0f * F32_U);
-    return b;
+    r.a = make_float4(-fx, -fy, -fz, (float)od);
+    const double thr = o2 - (double)E0 - (double)Eh * Eh * (1.0 + 1.0 / (double)BROAD_DELTA);
+    const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U);     // rounded down
+    r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);
+    const float bc = (float)(o2 - (double)E0) - __builtin_fabsf((float)o2) * (4.0f * F32_U);
+    r.c = make_float4(Eh * 1.00001f, bc, 0.0f, 0.0f);
+    return r;
 }
 
-// conservative discriminant of one record; hb and q are returned for the behind test
-DEV float broad_disc(const float4 r, const Broad& b, float& hb, float& q) {
-    hb = __builtin_fmaf(b.dz, r.z, __builtin_fmaf(b.dy, r.y, __builtin_fmaf(b.dx, r.x, b.od)));
-    q = __builtin_fmaf(b.mz, r.z, __builtin_fmaf(b.my, r.y, __builtin_fmaf(b.mx, r.x, r.w)));
-    const float t = b.K - q;
-    const float m = __builtin_fmaf(__builtin_fabsf(hb), b.k1, t);
-    return __builtin_fmaf(hb, hb, m);
+// s and hb' of one record (cx, cy, cz, R^2 - |c|^2) for one ray; nq is returned for the behind test
+DEV float broad_s(const float4 rec, const float4 ra, const float4 rb, float& hb, float& nq) {
+    hb = __builtin_fmaf(ra.z, rec.z, __builtin_fmaf(ra.y, rec.y, __builtin_fmaf(ra.x, rec.x, ra.w)));
+    nq = __builtin_fmaf(rb.z, rec.z, __builtin_fmaf(rb.y, rec.y, __builtin_fmaf(rb.x, rec.x, rec.w)));
+    return __builtin_fmaf(hb, hb, nq);
+}
+DEV bool broad_behind(float hb, float nq, const float4 rc) { return hb > rc.x && nq < rc.y; }
+
+// ---- per-path state and one segment of add_to_path -------------------------------------------
+enum { FL_FIRST_SEG = 1, FL_PV_REFLECT = 2 };
+
+struct PathState {
+    unsigned rng;
+    int px, py;
+    int sample;
+    int remaining;
+    int nverts;
+    int pv_mat;
+    int flags;
+    unsigned out_index;     // pixel slot in rgb / hit_ids
+    double n_cur;
+    double acc0, acc1, acc2;
+    d3 o, d;                // current ray; o is also the previous vertex's point once nverts > 0
+    d3 pv_n, pv_r;          // previous vertex: normal, mirror direction
+};
+
+// the stack of per-vertex throughput factors: element (k, c) lives at base[(3k + c) * stride]
+struct FactorStack {
+    double* base;
+    size_t stride;
+    DEV double get(int k, int c) const { return base[(size_t)(3 * k + c) * stride]; }
+    DEV void set(int k, int c, double v) const { base[(size_t)(3 * k + c) * stride] = v; }
+};
+
+// the camera ray of do_rays_i, main.cpp:255-270
+DEV void start_path(PathState& s, const KParams& kp) {
+    const double PI = 3.14159265358979323846;
+    double xs = rng_uniform(s.rng) - 0.5;
+    double ys = rng_uniform(s.rng) - 0.5;
+    d3 pix = dmk((double)(s.px - kp.width / 2 + xs) / kp.scale, (double)(kp.height / 2 - s.py + ys) / kp.scale, 0.0);
+    double theta = rng_uniform(s.rng) * 2.0 * PI;
+    double rad = rng_uniform(s.rng) * kp.lens;
+    double st, ct;
+    rtm::sincosd(theta, &st, &ct);
+    const d3 camera = dmk(0.0, 0.0, 40.0);
+    d3 org = dmk(camera.x + rad * ct, camera.y + rad * st, camera.z + 0.0);
+    d3 D = dnorm(dsub(pix, camera));
+    d3 C = dalong(camera, kp.focal, D);
+    s.o = org;
+    s.d = dnorm(dsub(C, org));
+    s.remaining = kp.depth;
+    s.n_cur = 1.0;
+    s.nverts = 0;
+    s.flags = FL_FIRST_SEG;
+}
+
+DEV void begin_pixel(PathState& s, unsigned item, const KParams& kp) {
+    s.out_index = kp.stream_mode ? (unsigned)(s.py * kp.width + s.px) : item;
+    s.sample = 0;
+    s.acc0 = s.acc1 = s.acc2 = 0.0;
+    start_path(s, kp);
+}
+
+// a path ended with radiance (c0,c1,c2): main.cpp:271-275.  Returns false when the lane's item is finished.
+DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, unsigned long long item_rays, const KParams& kp) {
+    s.acc0 = s.acc0 + c0; s.acc1 = s.acc1 + c1; s.acc2 = s.acc2 + c2;
+    s.sample++;
+    if (s.sample < kp.spp) {
+        start_path(s, kp);
+        return true;
+    }
+    const double n = (double)kp.spp;
+    double* out = kp.rgb + (size_t)s.out_index * 3;
+    out[0] = s.acc0 / n; out[1] = s.acc1 / n; out[2] = s.acc2 / n;
+    if (kp.stream_mode) {
+        // next pixel of this reference thread: x ascending, then y += num_threads (main.cpp:250-251)
+        s.px++;
+        if (s.px >= kp.width) { s.px = 0; s.py += kp.n_streams; }
+        if (s.py < kp.height) { begin_pixel(s, item, kp); return true; }
+        kp.stream_rays[item] = item_rays;
+    }
+    return false;
+}
+
+// One segment of add_to_path (main.cpp:126-183) after its closest hit `h` is known: record the hit id
+// of a camera ray, push the previous vertex's throughput factor (Path::trace, geometry.cpp:190-213),
+// then terminate the path or sample the next ray.  Returns false when the lane's item is finished.
+DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned item, unsigned long long item_rays,
+                 const KParams& kp) {
+    if (s.flags & FL_FIRST_SEG) {
+        if (kp.hit_ids) kp.hit_ids[(size_t)s.out_index * kp.spp + s.sample] = h.idx;
+        s.flags &= ~FL_FIRST_SEG;
+    }
+    if (h.idx < 0) return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);           // main.cpp:179-182
+    const PrimD* pi = kp.prims + h.idx;
+    const int kind = pi->kind;
+    d3 normal;
+    int mi;
+    if (kind == RT_KIND_SPHERE) { normal = dnorm(dsub(h.p, dmk(pi->a[0], pi->a[1], pi->a[2]))); mi = pi->mat0; }
+    else if (kind == RT_KIND_PLANE) { normal = dmk(pi->n[0], pi->n[1], pi->n[2]); mi = plane_material(*pi, h.p); }
+    else { normal = dmk(pi->n[0], pi->n[1], pi->n[2]); mi = pi->mat0; }
+    const MatD* m = kp.mats + mi;
+    const bool is_light = m->is_light != 0;
+    const bool dead_end = (!is_light) && s.remaining == 0 && kp.has_light;             // main.cpp:137-153: always black
+
+    if (s.nverts > 0 && !dead_end) {
+        const MatD* pm = kp.mats + s.pv_mat;
+        d3 w = dnorm(dsub(h.p, s.o));
+        double sp;
+        const double *dc, *sc;
+        if (s.flags & FL_PV_REFLECT) { sp = rtm::powd(ddot(s.pv_r, w), pm->sexp); dc = pm->diff; sc = pm->spec; }
+        else { sp = 1.0; dc = pm->rdiff; sc = pm->rspec; }
+        double dd = ddot(s.pv_n, w);
+        if (sp < 0.0) sp = 0.0;
+        if (dd < 0.0) dd = 0.0;
+        fst.set(s.nverts - 1, 0, dc[0] * dd + sc[0] * sp);
+        fst.set(s.nverts - 1, 1, dc[1] * dd + sc[1] * sp);
+        fst.set(s.nverts - 1, 2, dc[2] * dd + sc[2] * sp);
+    }
+
+    if (is_light) {                                                                    // main.cpp:132-135
+        double c0 = m->ref[0], c1 = m->ref[1], c2 = m->ref[2];
+        for (int k = s.nverts - 1; k >= 0; k--) {
+            c0 = c0 * fst.get(k, 0); c1 = c1 * fst.get(k, 1); c2 = c2 * fst.get(k, 2);
+        }
+        return end_path(s, c0, c1, c2, item, item_rays, kp);
+    }
+    if (dead_end) {
+        for (int k = 0; k < kp.light_draws; k++) rng_next(s.rng);                      // rand_point of the first light
+        return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);
+    }
+    if (s.nverts >= kp.max_verts) {
+        atomicOr(&kp.ctrl[1], ERR_STACK);
+        return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);
+    }
+    d3 fwd;
+    int change = 1;
+    double n2 = 1.0;
+    bool reflect = false;
+    const double rindex = m->rindex;
+    if (__builtin_fabs(rindex - s.n_cur) < 0.0001) {                                   // leaving, main.cpp:158-161
+        fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
+        change = 0;
+    } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                       // main.cpp:164-167
+        fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1]);
+        reflect = true;
+    } else {                                                                           // main.cpp:168-171
+        fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
+        n2 = rindex;
+    }
+    s.pv_n = normal;
+    s.pv_r = dneg(reflect_dir(s.d, normal));
+    s.pv_mat = mi;
+    s.flags = reflect ? (s.flags | FL_PV_REFLECT) : (s.flags & ~FL_PV_REFLECT);
+    s.nverts++;
+    s.o = h.p; s.d = fwd; s.remaining -= change; s.n_cur = n2;
+    return true;
+}
+
+// narrow phase on one candidate: the reference's double-precision test
+DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) {
+    const PrimD* pr = kp.prims + idx;
+    const int kind = pr->kind;
+    d3 p0;
+    if (kind == RT_KIND_SPHERE) p0 = sphere_point(*pr, o, d);
+    else if (kind == RT_KIND_PLANE) p0 = plane_point(dmk(pr->a[0], pr->a[1], pr->a[2]), dmk(pr->n[0], pr->n[1], pr->n[2]), o, d);
+    else p0 = face_point(*pr, kp.verts, o, d);
+    consider(p0, idx, o, h);
+}
+
+DEV void map_item_to_pixel(unsigned item, const KParams& kp, int& px, int& py) {
+    const int lr = (int)(item / (unsigned)kp.width);
+    px = (int)(item - (unsigned)lr * (unsigned)kp.width);
+    py = ((lr / kp.tile_rows) * kp.world + kp.rank) * kp.tile_rows + lr % kp.tile_rows;
 }
 
 enum { ST_NEED = 0, ST_ALIVE = 1, ST_DEAD = 2 };
 
+// ---- single-kernel renderer: persistent lanes, broad + narrow + shading in one loop ------------
+// Used for the reference-order validation mode (one lane per reference thread) and selectable for
+// the per-pixel mode (RT_MODE=mega); the per-pixel default is the three-kernel pipeline below.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
     extern __shared__ float4 lds[];
     const int lane = threadIdx.x & 63;
     const bool lockstep = kp.nchunks > 1;
-    const double PI = 3.14159265358979323846;
 
-    // ---- per-lane state
     int state = ST_NEED;
     unsigned item = 0;        // pixel mode: local pixel index; stream mode: stream number
-    unsigned out_index = 0;   // pixel slot in rgb / hit_ids
-    int px = 0, py = 0;
-    unsigned rng = 1;
-    int sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    d3 o = dmk(0, 0, 0), d = dmk(0, 0, 1);
-    int remaining = 0;
-    double n_cur = 1.0;
-    int nverts = 0;
-    bool first_seg = false;
-    d3 pv_p = dmk(0, 0, 0), pv_n = dmk(0, 0, 0), pv_r = dmk(0, 0, 0);
-    int pv_mat = 0;
-    bool pv_reflect = false;
+    PathState s;
+    s.rng = 1; s.px = s.py = 0; s.sample = 0; s.remaining = 0; s.nverts = 0; s.pv_mat = 0; s.flags = 0; s.out_index = 0;
+    s.n_cur = 1.0; s.acc0 = s.acc1 = s.acc2 = 0.0;
+    s.o = dmk(0, 0, 0); s.d = dmk(0, 0, 1); s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
     unsigned nrays = 0, ncand_total = 0;
     unsigned long long item_rays = 0;
-    double fst[RT_MAXV * 3];
+    double fst_mem[RT_MAXV * 3];
+    FactorStack fst; fst.base = fst_mem; fst.stride = 1;
     int cand[CAND_CAP];
 
     auto stage = [&](int c) {
         const ChunkDesc ch = kp.chunks[c];
         const float4* src = kp.records + ch.gofs;
         for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
-    };
-
-    // the camera ray of do_rays_i, main.cpp:255-270
-    auto start_path = [&]() {
-        double xs = rng_uniform(rng) - 0.5;
-        double ys = rng_uniform(rng) - 0.5;
-        d3 pix = dmk((double)(px - kp.width / 2 + xs) / kp.scale, (double)(kp.height / 2 - py + ys) / kp.scale, 0.0);
-        double theta = rng_uniform(rng) * 2.0 * PI;
-        double rad = rng_uniform(rng) * kp.lens;
-        double st, ct;
-        rtm::sincosd(theta, &st, &ct);
-        const d3 camera = dmk(0.0, 0.0, 40.0);
-        d3 org = dmk(camera.x + rad * ct, camera.y + rad * st, camera.z + 0.0);
-        d3 D = dnorm(dsub(pix, camera));
-        d3 C = dalong(camera, kp.focal, D);
-        o = org;
-        d = dnorm(dsub(C, org));
-        remaining = kp.depth;
-        n_cur = 1.0;
-        nverts = 0;
-        first_seg = true;
-    };
-
-    auto begin_pixel = [&]() {
-        out_index = kp.stream_mode ? (unsigned)(py * kp.width + px) : item;
-        sample = 0;
-        acc0 = acc1 = acc2 = 0.0;
-        start_path();
-    };
-
-    // a path ended with radiance (c0,c1,c2): main.cpp:271-275
-    auto end_path = [&](double c0, double c1, double c2) {
-        acc0 = acc0 + c0; acc1 = acc1 + c1; acc2 = acc2 + c2;
-        sample++;
-        if (sample < kp.spp) {
-            start_path();
-            return;
-        }
-        const double n = (double)kp.spp;
-        double* out = kp.rgb + (size_t)out_index * 3;
-        out[0] = acc0 / n; out[1] = acc1 / n; out[2] = acc2 / n;
-        if (kp.stream_mode) {
-            // next pixel of this reference thread: x ascending, then y += num_threads (main.cpp:250-251)
-            px++;
-            if (px >= kp.width) { px = 0; py += kp.n_streams; }
-            if (py < kp.height) { begin_pixel(); return; }
-            kp.stream_rays[item] = item_rays;
-        }
-        state = ST_NEED;
     };
 
     if (!lockstep) {
@@ -431,16 +547,14 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
                     item = base + rank;
                     if (item < kp.total_items) {
                         if (kp.stream_mode) {
-                            px = 0; py = (int)item;
-                            rng = 1;                                   // default-constructed / seed(0): state 1
+                            s.px = 0; s.py = (int)item;
+                            s.rng = 1;                                   // default-constructed / seed(0): state 1
                             item_rays = 0;
                         } else {
-                            const int lr = (int)(item / (unsigned)kp.width);
-                            px = (int)(item - (unsigned)lr * (unsigned)kp.width);
-                            py = ((lr / kp.tile_rows) * kp.world + kp.rank) * kp.tile_rows + lr % kp.tile_rows;
-                            rng = pixel_seed((unsigned)(py * kp.width + px), kp.frame_seed);
+                            map_item_to_pixel(item, kp, s.px, s.py);
+                            s.rng = pixel_seed((unsigned)(s.py * kp.width + s.px), kp.frame_seed);
                         }
-                        if (py < kp.height) { state = ST_ALIVE; begin_pixel(); }
+                        if (s.py < kp.height) { state = ST_ALIVE; begin_pixel(s, item, kp); }
                         else { if (kp.stream_mode) kp.stream_rays[item] = 0; state = ST_NEED; }
                     } else {
                         state = ST_DEAD;
@@ -451,7 +565,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
         const bool alive = (state == ST_ALIVE);
         if (lockstep) {
             if (!__syncthreads_or(alive ? 1 : 0)) {
-                if (__syncthreads_or(state == ST_NEED ? 1 : 0)) continue;   // stream-mode lanes that got an empty stream
+                if (__syncthreads_or(state == ST_NEED ? 1 : 0)) continue;   // a lane drew an empty stream: refill again
                 break;
             }
         } else {
@@ -466,24 +580,14 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
         h.len = __builtin_inf(); h.idx = -1;
         h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
         int ncand = 0;
-
-        // narrow phase: the reference's double-precision test on every candidate, in file order
         auto narrow = [&]() {
-            for (int k = 0; k < ncand; k++) {
-                const int idx = cand[k];
-                const PrimD pr = kp.prims[idx];
-                d3 p0;
-                if (pr.kind == RT_KIND_SPHERE) p0 = sphere_point(pr, o, d);
-                else if (pr.kind == RT_KIND_PLANE) p0 = plane_point(dmk(pr.a[0], pr.a[1], pr.a[2]), dmk(pr.n[0], pr.n[1], pr.n[2]), o, d);
-                else p0 = face_point(pr, kp.verts, o, d);
-                consider(p0, idx, o, h);
-            }
+            for (int k = 0; k < ncand; k++) narrow_one(cand[k], s.o, s.d, kp, h);
             ncand_total += (unsigned)ncand;
             ncand = 0;
         };
 
-        Broad bp;
-        if (alive) bp = broad_setup(o, d, kp);
+        RayRec rr;
+        if (alive) rr = broad_setup(s.o, s.d, kp.T, kp.cmax);
         for (int c = 0; c < kp.nchunks; c++) {
             if (lockstep) {
                 if (c > 0) __syncthreads();
@@ -495,94 +599,28 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
                 for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
                     const float4 r0 = lds[i], r1 = lds[i + 1], r2 = lds[i + 2], r3 = lds[i + 3];
                     float hb0, hb1, hb2, hb3, q0, q1, q2, q3;
-                    const float d0 = broad_disc(r0, bp, hb0, q0);
-                    const float d1 = broad_disc(r1, bp, hb1, q1);
-                    const float d2 = broad_disc(r2, bp, hb2, q2);
-                    const float d3_ = broad_disc(r3, bp, hb3, q3);
-                    if ((d0 >= 0.0f) | (d1 >= 0.0f) | (d2 >= 0.0f) | (d3_ >= 0.0f)) {
+                    const float s0 = broad_s(r0, rr.a, rr.b, hb0, q0);
+                    const float s1 = broad_s(r1, rr.a, rr.b, hb1, q1);
+                    const float s2 = broad_s(r2, rr.a, rr.b, hb2, q2);
+                    const float s3 = broad_s(r3, rr.a, rr.b, hb3, q3);
+                    const float thr = rr.b.w;
+                    if ((s0 >= thr) | (s1 >= thr) | (s2 >= thr) | (s3 >= thr)) {
                         const int base = ch.first_index + i;
-                        if (d0 >= 0.0f && !(hb0 > bp.behind_h && q0 > bp.behind_c)) cand[ncand++] = base;
-                        if (d1 >= 0.0f && !(hb1 > bp.behind_h && q1 > bp.behind_c)) cand[ncand++] = base + 1;
-                        if (d2 >= 0.0f && !(hb2 > bp.behind_h && q2 > bp.behind_c)) cand[ncand++] = base + 2;
-                        if (d3_ >= 0.0f && !(hb3 > bp.behind_h && q3 > bp.behind_c)) cand[ncand++] = base + 3;
+                        if (s0 >= thr && !broad_behind(hb0, q0, rr.c)) cand[ncand++] = base;
+                        if (s1 >= thr && !broad_behind(hb1, q1, rr.c)) cand[ncand++] = base + 1;
+                        if (s2 >= thr && !broad_behind(hb2, q2, rr.c)) cand[ncand++] = base + 2;
+                        if (s3 >= thr && !broad_behind(hb3, q3, rr.c)) cand[ncand++] = base + 3;
                         if (ncand > CAND_CAP - BROAD_UNROLL) narrow();
                     }
                 }
             }
         }
 
-        // ---- one segment of add_to_path, main.cpp:126-183
         if (alive) {
             narrow();
             nrays++;
             item_rays++;
-            const bool hit = h.idx >= 0;
-            if (first_seg) {
-                if (kp.hit_ids) kp.hit_ids[(size_t)out_index * kp.spp + sample] = h.idx;
-                first_seg = false;
-            }
-            if (!hit) {
-                end_path(0.0, 0.0, 0.0);                                     // main.cpp:179-182
-            } else {
-                const PrimD pi = kp.prims[h.idx];
-                d3 normal;
-                int mi;
-                if (pi.kind == RT_KIND_SPHERE) { normal = dnorm(dsub(h.p, dmk(pi.a[0], pi.a[1], pi.a[2]))); mi = pi.mat0; }
-                else if (pi.kind == RT_KIND_PLANE) { normal = dmk(pi.n[0], pi.n[1], pi.n[2]); mi = plane_material(pi, h.p); }
-                else { normal = dmk(pi.n[0], pi.n[1], pi.n[2]); mi = pi.mat0; }
-                const MatD* m = kp.mats + mi;
-                const bool is_light = m->is_light != 0;
-                const bool dead_end = (!is_light) && remaining == 0 && kp.has_light;   // main.cpp:137-153: always black
-
-                // throughput factor of the previous vertex, Path::trace geometry.cpp:190-213
-                if (nverts > 0 && !dead_end) {
-                    const MatD* pm = kp.mats + pv_mat;
-                    d3 w = dnorm(dsub(h.p, pv_p));
-                    double s;
-                    const double *dc, *sc;
-                    if (pv_reflect) { s = rtm::powd(ddot(pv_r, w), pm->sexp); dc = pm->diff; sc = pm->spec; }
-                    else { s = 1.0; dc = pm->rdiff; sc = pm->rspec; }
-                    double dd = ddot(pv_n, w);
-                    if (s < 0.0) s = 0.0;
-                    if (dd < 0.0) dd = 0.0;
-                    fst[(nverts - 1) * 3 + 0] = dc[0] * dd + sc[0] * s;
-                    fst[(nverts - 1) * 3 + 1] = dc[1] * dd + sc[1] * s;
-                    fst[(nverts - 1) * 3 + 2] = dc[2] * dd + sc[2] * s;
-                }
-
-                if (is_light) {                                              // main.cpp:132-135
-                    double c0 = m->ref[0], c1 = m->ref[1], c2 = m->ref[2];
-                    for (int k = nverts - 1; k >= 0; k--) {
-                        c0 = c0 * fst[k * 3 + 0]; c1 = c1 * fst[k * 3 + 1]; c2 = c2 * fst[k * 3 + 2];
-                    }
-                    end_path(c0, c1, c2);
-                } else if (dead_end) {
-                    for (int k = 0; k < kp.light_draws; k++) rng_next(rng);  // rand_point of the first light
-                    end_path(0.0, 0.0, 0.0);
-                } else if (nverts >= RT_MAXV) {
-                    atomicOr(&kp.ctrl[1], ERR_STACK);
-                    end_path(0.0, 0.0, 0.0);
-                } else {
-                    d3 fwd;
-                    int change = 1;
-                    double n2 = 1.0;
-                    bool reflect = false;
-                    const double rindex = m->rindex;
-                    if (__builtin_fabs(rindex - n_cur) < 0.0001) {           // leaving, main.cpp:158-161
-                        fwd = refraction_dir(d, normal, rindex, n_cur);
-                        change = 0;
-                    } else if (rindex == 0.0 || rng_next(rng) < 1073741823u) {   // main.cpp:164-167
-                        fwd = reflection_dir(d, normal, *m, rng, &kp.ctrl[1]);
-                        reflect = true;
-                    } else {                                                 // main.cpp:168-171
-                        fwd = refraction_dir(d, normal, rindex, n_cur);
-                        n2 = rindex;
-                    }
-                    pv_p = h.p; pv_n = normal; pv_r = dneg(reflect_dir(d, normal)); pv_mat = mi; pv_reflect = reflect;
-                    nverts++;
-                    o = h.p; d = fwd; remaining -= change; n_cur = n2;
-                }
-            }
+            if (!segment(s, h, fst, item, item_rays, kp)) state = ST_NEED;
         }
     }
 
@@ -592,6 +630,204 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
     if (lane == 0 && r) {
         atomicAdd((unsigned long long*)(kp.ctrl + 2), r);
         atomicAdd((unsigned long long*)(kp.ctrl + 4), cn);
+    }
+}
+
+// ---- three-kernel pipeline (per-pixel mode) ----------------------------------------------------
+// Path state lives in global memory, one slot per pixel of the batch, structure-of-arrays.  A frame is
+//   init_kernel                     camera ray of every pixel, queue 0 = all slots
+//   repeat: broad_kernel            FP32 scan of the LDS-resident records for every queued ray
+//           shade_kernel            FP64 narrow phase + segment(); surviving rays are packed into the
+//                                   next queue by ballot rank (one atomic per wave)
+// until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
+// small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
+constexpr int WF_CAND_CAP = 16;        // candidate slots per queued ray; overflow falls back to a full exact scan
+constexpr unsigned WF_OVERFLOW = 0xffffffffu;
+enum { SI_RNG = 0, SI_PX, SI_PY, SI_SAMPLE, SI_REMAINING, SI_NVERTS, SI_PVMAT, SI_FLAGS, SI_COUNT };
+enum { SD_NCUR = 0, SD_ACC = 1, SD_O = 4, SD_D = 7, SD_PVN = 10, SD_PVR = 13, SD_COUNT = 16 };
+
+struct WfParams {
+    KParams kp;
+    unsigned slots;            // pixel slots of this batch
+    unsigned item_base;        // first local pixel index of the batch
+    int iter;                  // iteration number: queue iter&1 is read, (iter+1)&1 written
+    int* si;                   // [SI_COUNT][slots]
+    double* sd;                // [SD_COUNT][slots]
+    double* stack;             // [3*max_verts][slots]
+    unsigned* queue[2];        // slot ids of the live rays
+    unsigned* counts;          // counts[i] = live rays entering iteration i
+    float4* rec[3];            // ray records by queue position
+    unsigned* cand;            // [slots][WF_CAND_CAP] by queue position
+    unsigned* cand_cnt;        // [slots]
+};
+
+DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
+    const size_t n = w.slots;
+    s.rng = (unsigned)w.si[SI_RNG * n + slot]; s.px = w.si[SI_PX * n + slot]; s.py = w.si[SI_PY * n + slot];
+    s.sample = w.si[SI_SAMPLE * n + slot]; s.remaining = w.si[SI_REMAINING * n + slot]; s.nverts = w.si[SI_NVERTS * n + slot];
+    s.pv_mat = w.si[SI_PVMAT * n + slot]; s.flags = w.si[SI_FLAGS * n + slot];
+    s.out_index = w.item_base + slot;
+    const double* d = w.sd + slot;
+    s.n_cur = d[SD_NCUR * n];
+    s.acc0 = d[(SD_ACC + 0) * n]; s.acc1 = d[(SD_ACC + 1) * n]; s.acc2 = d[(SD_ACC + 2) * n];
+    s.o = dmk(d[(SD_O + 0) * n], d[(SD_O + 1) * n], d[(SD_O + 2) * n]);
+    s.d = dmk(d[(SD_D + 0) * n], d[(SD_D + 1) * n], d[(SD_D + 2) * n]);
+    s.pv_n = dmk(d[(SD_PVN + 0) * n], d[(SD_PVN + 1) * n], d[(SD_PVN + 2) * n]);
+    s.pv_r = dmk(d[(SD_PVR + 0) * n], d[(SD_PVR + 1) * n], d[(SD_PVR + 2) * n]);
+}
+
+DEV void store_state(const WfParams& w, unsigned slot, const PathState& s) {
+    const size_t n = w.slots;
+    w.si[SI_RNG * n + slot] = (int)s.rng; w.si[SI_PX * n + slot] = s.px; w.si[SI_PY * n + slot] = s.py;
+    w.si[SI_SAMPLE * n + slot] = s.sample; w.si[SI_REMAINING * n + slot] = s.remaining; w.si[SI_NVERTS * n + slot] = s.nverts;
+    w.si[SI_PVMAT * n + slot] = s.pv_mat; w.si[SI_FLAGS * n + slot] = s.flags;
+    double* d = w.sd + slot;
+    d[SD_NCUR * n] = s.n_cur;
+    d[(SD_ACC + 0) * n] = s.acc0; d[(SD_ACC + 1) * n] = s.acc1; d[(SD_ACC + 2) * n] = s.acc2;
+    d[(SD_O + 0) * n] = s.o.x; d[(SD_O + 1) * n] = s.o.y; d[(SD_O + 2) * n] = s.o.z;
+    d[(SD_D + 0) * n] = s.d.x; d[(SD_D + 1) * n] = s.d.y; d[(SD_D + 2) * n] = s.d.z;
+    d[(SD_PVN + 0) * n] = s.pv_n.x; d[(SD_PVN + 1) * n] = s.pv_n.y; d[(SD_PVN + 2) * n] = s.pv_n.z;
+    d[(SD_PVR + 0) * n] = s.pv_r.x; d[(SD_PVR + 1) * n] = s.pv_r.y; d[(SD_PVR + 2) * n] = s.pv_r.z;
+}
+
+DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathState& s, int q) {
+    w.queue[q][pos] = slot;
+    const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
+    w.rec[0][pos] = r.a; w.rec[1][pos] = r.b; w.rec[2][pos] = r.c;
+}
+
+__global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < w.slots; slot += stride) {
+        PathState s;
+        const unsigned item = w.item_base + slot;
+        map_item_to_pixel(item, w.kp, s.px, s.py);
+        s.rng = pixel_seed((unsigned)(s.py * w.kp.width + s.px), w.kp.frame_seed);
+        s.pv_mat = 0; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
+        begin_pixel(s, item, w.kp);
+        store_state(w, slot, s);
+        emit_ray(w, slot, slot, s, 0);
+    }
+}
+
+// Two rays per lane: one LDS broadcast read feeds 16 VALU instructions, which keeps the LDS pipe
+// (4 cycles per ds_read_b128 per wave) well below the VALU time of the four SIMDs it serves.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
+    extern __shared__ float4 lds[];
+    const unsigned count = w.counts[w.iter];
+    if (count == 0) return;
+    const int nchunks = w.kp.nchunks;
+    const unsigned per_block = BLOCK * 2;
+    const unsigned nbatches = (count + per_block - 1) / per_block;
+    if (blockIdx.x >= nbatches) return;
+    const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    for (int c = 0; c < nchunks; c++) {
+        const ChunkDesc ch = w.kp.chunks[c];
+        if (c > 0) __syncthreads();
+        {
+            const float4* src = w.kp.records + ch.gofs;
+            for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
+        }
+        __syncthreads();
+        for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+            const unsigned pA = batch * per_block + threadIdx.x, pB = pA + BLOCK;
+            const bool vA = pA < count, vB = pB < count;
+            // dead lanes carry NaN constants: every comparison is false
+            const float4 aA = vA ? w.rec[0][pA] : nan4, bA = vA ? w.rec[1][pA] : nan4;
+            const float4 aB = vB ? w.rec[0][pB] : nan4, bB = vB ? w.rec[1][pB] : nan4;
+            unsigned nA = 0, nB = 0;
+            if (c > 0) { if (vA) nA = w.cand_cnt[pA]; if (vB) nB = w.cand_cnt[pB]; }
+            const float thrA = bA.w, thrB = bB.w;
+            auto keep = [&](unsigned pos, unsigned& n, float hb, float nq, int idx) {
+                if (n == WF_OVERFLOW) return;
+                const float4 rc = w.rec[2][pos];
+                if (broad_behind(hb, nq, rc)) return;
+                if (n >= (unsigned)WF_CAND_CAP) { n = WF_OVERFLOW; return; }
+                w.cand[(size_t)pos * WF_CAND_CAP + n] = (unsigned)idx;
+                n++;
+            };
+            float4 r0 = lds[0], r1 = lds[1], r2 = lds[2], r3 = lds[3];
+            for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
+                // prefetch the next group while this one is evaluated (the last prefetch re-reads the last group)
+                const int nx = (i + BROAD_UNROLL < ch.count) ? i + BROAD_UNROLL : i;
+                const float4 n0 = lds[nx], n1 = lds[nx + 1], n2 = lds[nx + 2], n3 = lds[nx + 3];
+                float hA0, hA1, hA2, hA3, qA0, qA1, qA2, qA3, hB0, hB1, hB2, hB3, qB0, qB1, qB2, qB3;
+                const float sA0 = broad_s(r0, aA, bA, hA0, qA0), sB0 = broad_s(r0, aB, bB, hB0, qB0);
+                const float sA1 = broad_s(r1, aA, bA, hA1, qA1), sB1 = broad_s(r1, aB, bB, hB1, qB1);
+                const float sA2 = broad_s(r2, aA, bA, hA2, qA2), sB2 = broad_s(r2, aB, bB, hB2, qB2);
+                const float sA3 = broad_s(r3, aA, bA, hA3, qA3), sB3 = broad_s(r3, aB, bB, hB3, qB3);
+                const bool fA = (sA0 >= thrA) | (sA1 >= thrA) | (sA2 >= thrA) | (sA3 >= thrA);
+                const bool fB = (sB0 >= thrB) | (sB1 >= thrB) | (sB2 >= thrB) | (sB3 >= thrB);
+                if (fA | fB) {
+                    const int base = ch.first_index + i;
+                    if (sA0 >= thrA) keep(pA, nA, hA0, qA0, base);
+                    if (sA1 >= thrA) keep(pA, nA, hA1, qA1, base + 1);
+                    if (sA2 >= thrA) keep(pA, nA, hA2, qA2, base + 2);
+                    if (sA3 >= thrA) keep(pA, nA, hA3, qA3, base + 3);
+                    if (sB0 >= thrB) keep(pB, nB, hB0, qB0, base);
+                    if (sB1 >= thrB) keep(pB, nB, hB1, qB1, base + 1);
+                    if (sB2 >= thrB) keep(pB, nB, hB2, qB2, base + 2);
+                    if (sB3 >= thrB) keep(pB, nB, hB3, qB3, base + 3);
+                }
+                r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+            }
+            if (vA) w.cand_cnt[pA] = nA;
+            if (vB) w.cand_cnt[pB] = nB;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
+    const unsigned count = w.counts[w.iter];
+    const int lane = threadIdx.x & 63;
+    const int qi = w.iter & 1, qo = qi ^ 1;
+    unsigned nrays = 0;
+    unsigned long long ncand_total = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of trips so that the ballot below sees whole waves
+    const unsigned trips = (count + stride - 1) / stride;
+    for (unsigned t = 0; t < trips; t++) {
+        const unsigned pos = t * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false;
+        PathState s;
+        unsigned slot = 0;
+        if (pos < count) {
+            slot = w.queue[qi][pos];
+            load_state(w, slot, s);
+            Hit h;
+            h.len = __builtin_inf(); h.idx = -1;
+            h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+            const unsigned n = w.cand_cnt[pos];
+            if (n == WF_OVERFLOW) {
+                // more candidates than slots: exact test against the whole list, file order
+                for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, s.o, s.d, w.kp, h);
+                ncand_total += (unsigned)w.kp.n_prims;
+            } else {
+                const unsigned* cl = w.cand + (size_t)pos * WF_CAND_CAP;
+                for (unsigned k = 0; k < n; k++) narrow_one((int)cl[k], s.o, s.d, w.kp, h);
+                ncand_total += n;
+            }
+            nrays++;
+            FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
+            alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
+            if (alive) store_state(w, slot, s);
+        }
+        // pack the surviving rays into the next queue: rank within the wave's ballot, one atomic per wave
+        const unsigned long long m = __ballot(alive);
+        if (m != 0ull) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&w.counts[w.iter + 1], (unsigned)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (alive) emit_ray(w, base + rank, slot, s, qo);
+        }
+    }
+    unsigned long long r = nrays, cn = ncand_total;
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
+    if (lane == 0 && r) {
+        atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
+        atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
     }
 }
 
@@ -617,13 +853,12 @@ __global__ void selftest_broad_kernel(int n, const double* o, const double* d, c
                                       double tx, double ty, double tz, int* flag) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    KParams kp;
-    kp.cmax = cmax; kp.T[0] = tx; kp.T[1] = ty; kp.T[2] = tz;
-    Broad b = broad_setup(dmk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dmk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), kp);
-    float hb, q;
-    float disc = broad_disc(rec[i], b, hb, q);
+    const double T[3] = {tx, ty, tz};
+    const RayRec r = broad_setup(dmk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dmk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), T, cmax);
+    float hb, nq;
+    const float sv = broad_s(rec[i], r.a, r.b, hb, nq);
     int f = 0;
-    if (disc >= 0.0f) f = (hb > b.behind_h && q > b.behind_c) ? 2 : 1;   // 2 = culled as "behind"
+    if (sv >= r.b.w) f = broad_behind(hb, nq, r.c) ? 2 : 1;   // 2 = dropped as "behind"
     flag[i] = f;
 }
 
@@ -640,6 +875,8 @@ struct rt_context {
     double scale = 0, lens = 0, focal = 0;
     unsigned frame_seed = 0;
     int has_light = 0, light_draws = 0;
+    bool regular_paths = false;   // every path ends within 2*depth+1 segments (an emitter exists, no index-1 glass)
+    int n_prims = 0;
     uint64_t n_spheres = 0, n_planes = 0, n_faces = 0, n_face_verts = 0;
     // device scene
     void* d_records = nullptr;
@@ -653,6 +890,15 @@ struct rt_context {
     double T[3] = {0, 0, 0};
     unsigned* d_ctrl = nullptr;
     unsigned long long* d_stream_rays = nullptr; int stream_cap = 0;
+    // pipeline state (per-pixel mode), sized for wf_slots pixel slots and wf_verts stack entries
+    size_t wf_slots = 0; int wf_verts = 0; int wf_iters = 0;
+    int* wf_si = nullptr; double* wf_sd = nullptr; double* wf_stack = nullptr;
+    unsigned* wf_queue[2] = {nullptr, nullptr};
+    unsigned* wf_counts = nullptr;
+    float4* wf_rec[3] = {nullptr, nullptr, nullptr};
+    unsigned* wf_cand = nullptr; unsigned* wf_cand_cnt = nullptr;
+    std::vector<hipEvent_t> broad_ev;   // pairs around every broad_kernel launch when timing_detail is on
+    int broad_ev_used = 0;
     // scratch outputs of rt_render
     double* d_rgb = nullptr; size_t d_rgb_bytes = 0;
     int32_t* d_hits = nullptr; size_t d_hits_bytes = 0;
@@ -660,9 +906,14 @@ struct rt_context {
     bool events_pending = false;
     int last_streams = 0;
     rt_timing timing{};
-    int block = 256;
-    int grid_mult = 0;     // workgroups per CU, 0 = ask the occupancy API
-    int chunk_records = 4096;
+    // options
+    int mode = RT_MODE_PIPELINE;
+    int timing_detail = 0;
+    int block = 256;           // single-kernel renderer: workgroup size
+    int broad_block = 512;     // broad_kernel workgroup size
+    int grid_mult = 0;         // workgroups per CU, 0 = ask the occupancy API
+    int chunk_records = 8192;  // LDS window in records (16 bytes each)
+    size_t max_slots = (size_t)1 << 25;
 };
 
 namespace {
@@ -684,11 +935,53 @@ void free_scene(rt_context* h) {
     h->have_scene = false;
 }
 
-// largest float <= x
-float round_down_f(double x) {
+void free_pipeline(rt_context* h) {
+    hipFree(h->wf_si); hipFree(h->wf_sd); hipFree(h->wf_stack); hipFree(h->wf_queue[0]); hipFree(h->wf_queue[1]);
+    hipFree(h->wf_counts); hipFree(h->wf_rec[0]); hipFree(h->wf_rec[1]); hipFree(h->wf_rec[2]);
+    hipFree(h->wf_cand); hipFree(h->wf_cand_cnt);
+    h->wf_si = nullptr; h->wf_sd = nullptr; h->wf_stack = nullptr; h->wf_queue[0] = h->wf_queue[1] = nullptr;
+    h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = h->wf_rec[2] = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr;
+    h->wf_slots = 0; h->wf_verts = 0; h->wf_iters = 0;
+}
+
+// smallest float >= x
+float round_up_f(double x) {
     float f = (float)x;
-    if ((double)f > x) f = nextafterf(f, -INFINITY);
+    if ((double)f < x) f = nextafterf(f, INFINITY);
     return f;
+}
+
+// the broad-phase record of a bounding sphere (centre c relative to T, radius R): (c, R^2 - |c|^2) with the
+// radius inflated for the rounding of the centre to float; returns |c| + R for the scene-wide cmax
+double make_record(const double* c, double R, float* out) {
+    double c2 = 0, cn = 0;
+    for (int k = 0; k < 3; k++) {
+        out[k] = (float)c[k];
+        c2 += (double)out[k] * out[k];
+        cn += c[k] * c[k];
+    }
+    const double Rr = R * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
+    out[3] = round_up_f(Rr * Rr - c2);
+    return sqrt(cn) + Rr;
+}
+
+void fill_kparams(rt_context* h, KParams& kp) {
+    memset(&kp, 0, sizeof(kp));
+    kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
+    kp.scale = h->scale; kp.lens = h->lens; kp.focal = h->focal; kp.frame_seed = h->frame_seed;
+    kp.has_light = h->has_light; kp.light_draws = h->light_draws;
+    kp.tile_rows = 1; kp.rank = 0; kp.world = 1;
+    kp.nchunks = h->nchunks;
+    kp.n_prims = h->n_prims;
+    kp.max_verts = RT_MAXV;
+    kp.cmax = h->cmax;
+    for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
+    kp.records = (const float4*)h->d_records;
+    kp.chunks = (const ChunkDesc*)h->d_chunks;
+    kp.prims = (const PrimD*)h->d_prims;
+    kp.verts = (const double*)h->d_verts;
+    kp.mats = (const MatD*)h->d_mats;
+    kp.ctrl = h->d_ctrl;
 }
 
 template <int BLOCK>
@@ -710,6 +1003,29 @@ hipError_t launch_render(rt_context* h, const KParams& kp, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int BLOCK>
+hipError_t launch_broad(rt_context* h, const WfParams& w, unsigned grid, hipStream_t st) {
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipLaunchKernelGGL(broad_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, st, w);
+    return hipGetLastError();
+}
+
+template <int BLOCK>
+hipError_t broad_grid(rt_context* h, unsigned* grid) {
+    auto kern = broad_kernel<BLOCK>;
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = h->grid_mult;
+    if (per_cu <= 0) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+    }
+    *grid = (unsigned)(h->cu_count * per_cu);
+    return hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
@@ -728,20 +1044,49 @@ int rt_create(rt_handle* out, int device) {
     if (hipMalloc((void**)&h->d_ctrl, 64) != hipSuccess) { delete h; return RT_ERR_HIP; }
     hipEventCreate(&h->ev0);
     hipEventCreate(&h->ev1);
-    if (const char* e = getenv("RT_BLOCK")) { int b = atoi(e); if (b == 256 || b == 512 || b == 1024) h->block = b; }
-    if (const char* e = getenv("RT_WG_PER_CU")) h->grid_mult = atoi(e);
-    if (const char* e = getenv("RT_CHUNK_RECORDS")) { int k = atoi(e); if (k >= 64 && k <= 9728) h->chunk_records = k / BROAD_UNROLL * BROAD_UNROLL; }
+    // tuning knobs for experiments; rt_set_option is the API for the same values
+    if (const char* e = getenv("RT_MODE")) rt_set_option(h, RT_OPT_MODE, strcmp(e, "mega") == 0 ? RT_MODE_SINGLE_KERNEL : RT_MODE_PIPELINE);
+    if (const char* e = getenv("RT_BLOCK")) rt_set_option(h, RT_OPT_BLOCK, atoi(e));
+    if (const char* e = getenv("RT_BROAD_BLOCK")) rt_set_option(h, RT_OPT_BROAD_BLOCK, atoi(e));
+    if (const char* e = getenv("RT_WG_PER_CU")) rt_set_option(h, RT_OPT_WG_PER_CU, atoi(e));
+    if (const char* e = getenv("RT_CHUNK_RECORDS")) rt_set_option(h, RT_OPT_CHUNK_RECORDS, atoi(e));
     *out = h;
     return RT_OK;
+}
+
+int rt_set_option(rt_handle h, int key, int value) {
+    if (!h) return RT_ERR_ARG;
+    switch (key) {
+        case RT_OPT_MODE:
+            if (value != RT_MODE_PIPELINE && value != RT_MODE_SINGLE_KERNEL) return fail(h, RT_ERR_ARG, "rt_set_option: bad mode");
+            h->mode = value; return RT_OK;
+        case RT_OPT_TIMING_DETAIL: h->timing_detail = value != 0; return RT_OK;
+        case RT_OPT_BLOCK:
+            if (value != 256 && value != 512 && value != 1024) return fail(h, RT_ERR_ARG, "rt_set_option: block must be 256, 512 or 1024");
+            h->block = value; return RT_OK;
+        case RT_OPT_BROAD_BLOCK:
+            if (value != 256 && value != 512 && value != 1024) return fail(h, RT_ERR_ARG, "rt_set_option: block must be 256, 512 or 1024");
+            h->broad_block = value; return RT_OK;
+        case RT_OPT_WG_PER_CU: h->grid_mult = value > 0 ? value : 0; return RT_OK;
+        case RT_OPT_CHUNK_RECORDS:   // takes effect at the next rt_upload_scene
+            if (value < 64 || value > 9728) return fail(h, RT_ERR_ARG, "rt_set_option: LDS window must be 64..9728 records");
+            h->chunk_records = value / BROAD_UNROLL * BROAD_UNROLL; return RT_OK;
+        case RT_OPT_MAX_SLOTS:
+            if (value < 1) return fail(h, RT_ERR_ARG, "rt_set_option: max slots must be positive");
+            h->max_slots = (size_t)value; return RT_OK;
+        default: return fail(h, RT_ERR_ARG, "rt_set_option: unknown key");
+    }
 }
 
 void rt_destroy(rt_handle h) {
     if (!h) return;
     hipSetDevice(h->device);
     free_scene(h);
+    free_pipeline(h);
     hipFree(h->d_ctrl); hipFree(h->d_rgb); hipFree(h->d_hits); hipFree(h->d_stream_rays);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->broad_ev) hipEventDestroy(e);
     delete h;
 }
 
@@ -892,20 +1237,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         }
         float r4[4];
         if (br[i] < 0) {
-            r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = -INFINITY;       // unbounded: q = -inf, always kept, never "behind"
+            r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = INFINITY;        // unbounded: always kept, never "behind"
         } else {
-            float cf[3];
-            double c2 = 0, cn = 0;
-            for (int k = 0; k < 3; k++) {
-                cf[k] = (float)(bc[(size_t)i * 3 + k] - T[k]);
-                c2 += (double)cf[k] * cf[k];
-                cn += (bc[(size_t)i * 3 + k] - T[k]) * (bc[(size_t)i * 3 + k] - T[k]);
-            }
-            // radius inflated for the rounding of the centre (<= u |c| per component) and a relative 1e-6
-            double Rr = br[i] * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
-            r4[0] = cf[0]; r4[1] = cf[1]; r4[2] = cf[2];
-            r4[3] = round_down_f(c2 - Rr * Rr);
-            if (sqrt(cn) + Rr > cmax) cmax = sqrt(cn) + Rr;
+            double c[3];
+            for (int k = 0; k < 3; k++) c[k] = bc[(size_t)i * 3 + k] - T[k];
+            const double ext = make_record(c, br[i], r4);
+            if (ext > cmax) cmax = ext;
         }
         rec.insert(rec.end(), r4, r4 + 4);
         chunks.back().count++;
@@ -951,6 +1288,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         int k = (int)prims[(size_t)first_light * RT_PR_STRIDE + RT_PR_KIND];
         h->light_draws = (k == RT_KIND_PLANE) ? 0 : 2;   // rand_point, geometry.cpp:120,145-150,175-179
     }
+    // paths are bounded by 2*depth+1 segments when an emitter exists (main.cpp:137-153 ends a path at depth 0)
+    // and no transparent material has an index within 1e-4 of 1 (such a hit would always count as "leaving")
+    bool regular = first_light >= 0;
+    for (int i = 0; i < n_mats; i++) if (fabs(mats[(size_t)i * RT_MT_STRIDE + RT_MT_RINDEX] - 1.0) < 0.0002) regular = false;
+    h->regular_paths = regular;
+    h->n_prims = n_prims;
     h->nchunks = (int)chunks.size();
     h->max_chunk_records = maxrec;
     h->cmax = (float)(cmax * (1.0 + 1e-6)) ;
@@ -965,15 +1308,10 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     return RT_OK;
 }
 
-static int render_common(rt_handle h, int stream_mode, int tile_rows, int rank, int world, double* d_rgb,
-                         int32_t* d_hit_ids, void* stream) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
+static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int rank, int world, double* d_rgb,
+                                int32_t* d_hit_ids, hipStream_t st) {
     KParams kp;
-    memset(&kp, 0, sizeof(kp));
-    kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
-    kp.scale = h->scale; kp.lens = h->lens; kp.focal = h->focal; kp.frame_seed = h->frame_seed;
-    kp.has_light = h->has_light; kp.light_draws = h->light_draws;
+    fill_kparams(h, kp);
     kp.tile_rows = tile_rows; kp.rank = rank; kp.world = world;
     kp.stream_mode = stream_mode;
     if (stream_mode) {
@@ -991,15 +1329,7 @@ static int render_common(rt_handle h, int stream_mode, int tile_rows, int rank, 
         kp.total_items = (unsigned)((uint64_t)rows * (uint64_t)h->width);
     }
     h->last_streams = stream_mode ? h->num_threads : 0;
-    kp.nchunks = h->nchunks;
-    kp.cmax = h->cmax;
-    for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
-    kp.records = (const float4*)h->d_records;
-    kp.chunks = (const ChunkDesc*)h->d_chunks;
-    kp.prims = (const PrimD*)h->d_prims;
-    kp.verts = (const double*)h->d_verts;
-    kp.mats = (const MatD*)h->d_mats;
-    kp.rgb = d_rgb; kp.hit_ids = d_hit_ids; kp.ctrl = h->d_ctrl;
+    kp.rgb = d_rgb; kp.hit_ids = d_hit_ids;
     HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 64, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (kp.total_items > 0) {
@@ -1010,8 +1340,100 @@ static int render_common(rt_handle h, int stream_mode, int tile_rows, int rank, 
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("render kernel launch: ") + hipGetErrorString(e));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, st));
+    h->broad_ev_used = 0;
     h->events_pending = true;
     return RT_OK;
+}
+
+// (re)allocate the pipeline's per-slot state for `slots` pixel slots
+static int ensure_pipeline(rt_handle h, size_t slots, int verts, int iters) {
+    if (h->wf_slots >= slots && h->wf_verts >= verts && h->wf_iters >= iters) return RT_OK;
+    free_pipeline(h);
+    HIP_TRY(h, hipMalloc((void**)&h->wf_si, slots * SI_COUNT * sizeof(int)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_sd, slots * SD_COUNT * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_stack, slots * (size_t)verts * 3 * sizeof(double)));
+    for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_queue[q], slots * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_counts, ((size_t)iters + 2) * sizeof(unsigned)));
+    for (int q = 0; q < 3; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_rec[q], slots * sizeof(float4)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_cand, slots * WF_CAND_CAP * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_cand_cnt, slots * sizeof(unsigned)));
+    h->wf_slots = slots; h->wf_verts = verts; h->wf_iters = iters;
+    return RT_OK;
+}
+
+__global__ void set_count_kernel(unsigned* counts, unsigned n_counts, unsigned first) {
+    for (unsigned i = threadIdx.x; i < n_counts; i += blockDim.x) counts[i] = (i == 0) ? first : 0u;
+}
+
+static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids, hipStream_t st) {
+    const int rows = rt_rows_for_rank(h->height, tile_rows, rank, world);
+    const uint64_t total = (uint64_t)rows * (uint64_t)h->width;
+    // longest possible path in segments, and with it the number of broad/shade rounds a pixel can need
+    const int verts = h->regular_paths ? (2 * h->depth > 0 ? 2 * h->depth : 1) : RT_MAXV;
+    const int iters = h->spp * (verts + 1);
+    const size_t slots_cap = total < h->max_slots ? (size_t)(total ? total : 1) : h->max_slots;
+    int rc = ensure_pipeline(h, slots_cap, verts, iters);
+    if (rc != RT_OK) return rc;
+    WfParams w;
+    fill_kparams(h, w.kp);
+    w.kp.tile_rows = tile_rows; w.kp.rank = rank; w.kp.world = world;
+    w.kp.max_verts = verts;
+    w.kp.total_items = (unsigned)total;
+    w.kp.rgb = d_rgb; w.kp.hit_ids = d_hit_ids;
+    w.si = h->wf_si; w.sd = h->wf_sd; w.stack = h->wf_stack;
+    w.queue[0] = h->wf_queue[0]; w.queue[1] = h->wf_queue[1];
+    w.counts = h->wf_counts;
+    for (int q = 0; q < 3; q++) w.rec[q] = h->wf_rec[q];
+    w.cand = h->wf_cand; w.cand_cnt = h->wf_cand_cnt;
+    unsigned bgrid = 1;
+    hipError_t e;
+    if (h->broad_block == 1024) e = broad_grid<1024>(h, &bgrid);
+    else if (h->broad_block == 256) e = broad_grid<256>(h, &bgrid);
+    else e = broad_grid<512>(h, &bgrid);
+    if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
+    const unsigned sgrid = (unsigned)h->cu_count * 8u;
+    h->last_streams = 0;
+    h->broad_ev_used = 0;
+    if (h->timing_detail) {
+        const size_t need = (size_t)2 * iters * ((total + slots_cap - 1) / slots_cap ? (total + slots_cap - 1) / slots_cap : 1);
+        while (h->broad_ev.size() < need) { hipEvent_t ev; HIP_TRY(h, hipEventCreate(&ev)); h->broad_ev.push_back(ev); }
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 64, st));
+    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    for (uint64_t base = 0; base < total; base += slots_cap) {
+        const uint64_t n = total - base < slots_cap ? total - base : slots_cap;
+        w.slots = (unsigned)n;
+        w.item_base = (unsigned)base;
+        hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(256), 0, st, w.counts, (unsigned)iters + 2u, (unsigned)n);
+        w.iter = 0;
+        unsigned igrid = (unsigned)((n + 255) / 256);
+        if (igrid > (unsigned)h->cu_count * 16u) igrid = (unsigned)h->cu_count * 16u;
+        hipLaunchKernelGGL(init_kernel, dim3(igrid), dim3(256), 0, st, w);
+        for (int it = 0; it < iters; it++) {
+            w.iter = it;
+            if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
+            if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, st);
+            else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, st);
+            else e = launch_broad<512>(h, w, bgrid, st);
+            if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
+            if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
+            hipLaunchKernelGGL(shade_kernel, dim3(sgrid), dim3(256), 0, st, w);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("pipeline launch: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    h->events_pending = true;
+    return RT_OK;
+}
+
+static int render_common(rt_handle h, int stream_mode, int tile_rows, int rank, int world, double* d_rgb,
+                         int32_t* d_hit_ids, void* stream) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (stream_mode || h->mode == RT_MODE_SINGLE_KERNEL)
+        return render_single_kernel(h, stream_mode, tile_rows, rank, world, d_rgb, d_hit_ids, st);
+    return render_pipeline(h, tile_rows, rank, world, d_rgb, d_hit_ids, st);
 }
 
 int rt_render_rows_device(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids, void* stream) {
@@ -1040,6 +1462,11 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     HIP_TRY(h, hipMemcpy(ctrl, h->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     uint64_t r = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
     h->timing.kernel_ms = ms;
+    h->timing.broad_ms = 0.0;
+    for (int i = 0; i + 1 < h->broad_ev_used; i += 2) {
+        float bms = 0;
+        if (hipEventElapsedTime(&bms, h->broad_ev[i], h->broad_ev[i + 1]) == hipSuccess) h->timing.broad_ms += bms;
+    }
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
     h->timing.sphere_tests = r * h->n_spheres;
@@ -1125,13 +1552,8 @@ int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* d
     std::vector<float> rec((size_t)n * 4);
     double cmax = 0;
     for (int i = 0; i < n; i++) {
-        double c2 = 0, cn = 0;
-        float cf[3];
-        for (int k = 0; k < 3; k++) { cf[k] = (float)centres[3 * (size_t)i + k]; c2 += (double)cf[k] * cf[k]; cn += centres[3 * (size_t)i + k] * centres[3 * (size_t)i + k]; }
-        double Rr = fabs(radii[i]) * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
-        rec[4 * (size_t)i] = cf[0]; rec[4 * (size_t)i + 1] = cf[1]; rec[4 * (size_t)i + 2] = cf[2];
-        rec[4 * (size_t)i + 3] = round_down_f(c2 - Rr * Rr);
-        if (sqrt(cn) + Rr > cmax) cmax = sqrt(cn) + Rr;
+        const double ext = make_record(centres + 3 * (size_t)i, fabs(radii[i]), &rec[4 * (size_t)i]);
+        if (ext > cmax) cmax = ext;
     }
     double *dO = nullptr, *dD = nullptr; float4* dR = nullptr; int* dF = nullptr;
     HIP_TRY(h, hipMalloc((void**)&dO, (size_t)n * 24));

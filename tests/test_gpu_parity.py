@@ -124,6 +124,28 @@ def test_golden_synthetic_scenes_match_oracle(renderer, golden_dir, name):
     _compare(renderer, sc, name + "[streams]", streams=True)
 
 
+def test_single_kernel_and_pipeline_agree(renderer):
+    """Both renderers (three-kernel pipeline, persistent single kernel) and a pipeline forced to work in
+    several pixel batches and several LDS windows give the same bits."""
+    _, sc = synth.make("c5", width=128, spp=2)
+    o = po.render(sc, policy=po.POLICY_DEV, rng_mode=po.RNG_PIXEL, want_hits=True)
+    try:
+        for mode, slots, window in ((api.MODE_PIPELINE, 1 << 25, 8192), (api.MODE_SINGLE_KERNEL, 1 << 25, 8192),
+                                    (api.MODE_PIPELINE, 3000, 1000), (api.MODE_SINGLE_KERNEL, 1 << 25, 1000)):
+            renderer.set_option(api.OPT_MODE, mode)
+            renderer.set_option(api.OPT_MAX_SLOTS, slots)
+            renderer.set_option(api.OPT_CHUNK_RECORDS, window)
+            renderer.upload(sc)
+            g = renderer.render(want_hits=True)
+            assert g["rays"] == int(o["rays"].sum())
+            assert (g["hits"] == o["hits"]).all()
+            assert bits_equal(g["rgb"], o["rgb"]).all(), (mode, slots, window)
+    finally:
+        renderer.set_option(api.OPT_MODE, api.MODE_PIPELINE)
+        renderer.set_option(api.OPT_MAX_SLOTS, 1 << 25)
+        renderer.set_option(api.OPT_CHUNK_RECORDS, 8192)
+
+
 @pytest.mark.parametrize("cfg,width,kw", [("c2", 480, {}), ("c3", 256, {}), ("c4", 128, {}), ("c5", 96, dict(spp=2))])
 def test_baseline_configs_reduced(renderer, cfg, width, kw):
     _, sc = synth.make(cfg, width=width, **kw)
