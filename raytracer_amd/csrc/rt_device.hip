@@ -62,7 +62,7 @@ constexpr unsigned ERR_REJECT_GUARD = 1u, ERR_STACK = 2u;
 constexpr int REJECT_GUARD_ITERS = 1 << 20;
 constexpr float F32_U = 5.9604645e-8f;         // 2^-24, unit roundoff of float
 
-struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to BROAD_UNROLL
+struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to a multiple of 32
 
 struct PrimD {               // 96 bytes, indexed by file order: the narrow phase's exact data
     double a[3];             // sphere centre | plane point | face verts[0]
@@ -71,6 +71,11 @@ struct PrimD {               // 96 bytes, indexed by file order: the narrow phas
     int kind, mat0, mat1, voff;
     int vcnt, pad0, pad1, pad2;
 };
+
+// One face vertex with the two quantities Face::intersect (geometry.cpp:162-166) derives from the vertex
+// list for every ray: e = v_i - v_i+1 and to_next = e.(v_i - v_i+2), computed once on the host with the
+// same double operations.
+struct FaceV { double v[3]; double e[3]; double to_next; double pad; };
 
 struct MatD {                // struct Material (geometry.hpp:18-29) in double
     double ref[3], diff[3], spec[3], rdiff[3], rspec[3];
@@ -95,7 +100,7 @@ struct KParams {
     const float4* records;
     const ChunkDesc* chunks;
     const PrimD* prims;
-    const double* verts;
+    const FaceV* verts;
     const MatD* mats;
     double* rgb;
     int* hit_ids;
@@ -169,6 +174,9 @@ DEV d3 sphere_point(const PrimD& s, d3 o, d3 d) {
     d3 oc = dsub(o, dmk(s.a[0], s.a[1], s.a[2]));
     double b = 2.0 * ddot(d, oc);
     double c = ddot(oc, oc) - s.radius * s.radius;
+    // Origin outside and centre behind: with b > 0 and c > 0 the rounded sqrt(b*b - 4c) cannot exceed b
+    // (sqrt(fl(b*b)) rounds to b), so both roots fail t >= 0.001 and the reference returns a NaN point too.
+    if (b > 0.0 && c > 0.0) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
     double sq = __builtin_sqrt(b * b - 4.0 * c);
     double t = (-b - sq) / 2.0;
     if (t < RT_EPS) t = (-b + sq) / 2.0;
@@ -177,26 +185,26 @@ DEV d3 sphere_point(const PrimD& s, d3 o, d3 d) {
 }
 // Plane::intersect, geometry.cpp:99-105
 DEV d3 plane_point(d3 P, d3 n, d3 o, d3 d) {
-    double t = ddot(dsub(P, o), n) / ddot(n, d);
+    const double num = ddot(dsub(P, o), n), den = ddot(n, d);
+    // a correctly rounded quotient keeps the sign of the exact one: opposite signs give t < 0 < 0.001
+    if ((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0)) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+    double t = num / den;
     const double inf = __builtin_inf();
     if (t < RT_EPS) t = __builtin_nan("");
     if (t == inf || t == -inf) t = __builtin_nan("");
     return dalong(o, t, d);
 }
 // Face::intersect, geometry.cpp:160-168
-DEV d3 face_point(const PrimD& f, const double* verts, d3 o, d3 d) {
+DEV d3 face_point(const PrimD& f, const FaceV* verts, d3 o, d3 d) {
     d3 p = plane_point(dmk(f.a[0], f.a[1], f.a[2]), dmk(f.n[0], f.n[1], f.n[2]), o, d);
+    if (dnan(p.x)) return p;                 // plane missed: every comparison below would be false anyway
     const int num = f.vcnt;
-    const double* v = verts + (size_t)f.voff * 3;
+    const FaceV* v = verts + f.voff;
     bool miss = false;
     for (int i = 0; i < num; i++) {
-        const int i1 = (i + 1 < num) ? i + 1 : i + 1 - num;
-        const int i2 = (i + 2) % num;
-        d3 vi = dmk(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
-        d3 e = dsub(vi, dmk(v[3 * i1], v[3 * i1 + 1], v[3 * i1 + 2]));
-        double to_p = ddot(e, dsub(vi, p));
-        double to_next = ddot(e, dsub(vi, dmk(v[3 * i2], v[3 * i2 + 1], v[3 * i2 + 2])));
-        if (to_p * to_next < 0.0) miss = true;
+        const FaceV fv = v[i];
+        double to_p = ddot(dmk(fv.e[0], fv.e[1], fv.e[2]), dsub(dmk(fv.v[0], fv.v[1], fv.v[2]), p));
+        if (to_p * fv.to_next < 0.0) miss = true;
     }
     if (miss) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
     return p;
@@ -217,43 +225,34 @@ DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
     return dadd(dadd(a, b), c);
 }
 
-// get_reflection_ray, main.cpp:47-104.  Returns the new direction (not re-normalised).
+// get_reflection_ray, main.cpp:47-104.  Returns the new direction (not re-normalised).  The glossy
+// branch (:48-77, power-cosine lobe about the mirror direction, rejection loop) and the diffuse branch
+// (:78-103, uniform hemisphere about the normal) build their sample the same way about different axes;
+// they share one instruction stream here, each lane keeping its own branch's operation sequence.
 DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* err) {
     const double PI = 3.14159265358979323846;
     const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
-    if (rng_next(rng) < m.gloss_thr) {
-        d3 r = dneg(reflect_dir(d, normal));
-        double theta = rtm::acosd(r.z);
-        d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), r));
-        double sint, cost;
-        rtm::sincosd(theta, &sint, &cost);
-        const double inv_exp = 1.0 / m.sexp;
-        d3 nd = dmk(0.0, 0.0, 0.0);
-        for (int iter = 0;; iter++) {
-            double u = rtm::powd(rtm::cosd(rng_uniform(rng) * PI / 2.0), inv_exp);
-            double phi = rng_uniform(rng) * 2.0 * PI;
-            double sr = __builtin_sqrt(1.0 - u * u);
-            double sp, cp;
-            rtm::sincosd(phi, &sp, &cp);
-            d3 v = dmk(sr * cp, sr * sp, u);
-            nd = flat ? v : rotate3(v, n, cost, sint);
-            if (ddot(nd, normal) >= 0.0) break;
-            if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); break; }
-        }
-        return nd;
-    } else {
-        double theta = rtm::acosd(normal.z);
-        d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), normal));
-        double sint, cost;
-        rtm::sincosd(theta, &sint, &cost);
-        double u = rng_uniform(rng);
-        double phi = rng_uniform(rng) * 2.0 * PI;
-        double sr = __builtin_sqrt(1.0 - u * u);
+    const bool glossy = rng_next(rng) < m.gloss_thr;
+    const d3 axis = glossy ? dneg(reflect_dir(d, normal)) : normal;
+    const double theta = rtm::acosd(axis.z);
+    const d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), axis));
+    double sint, cost;
+    rtm::sincosd(theta, &sint, &cost);
+    const double inv_exp = 1.0 / m.sexp;
+    d3 nd = dmk(0.0, 0.0, 0.0);
+    for (int iter = 0;; iter++) {
+        const double u1 = rng_uniform(rng);
+        const double u = glossy ? rtm::powd(rtm::cosd(u1 * PI / 2.0), inv_exp) : u1;
+        const double phi = rng_uniform(rng) * 2.0 * PI;
+        const double sr = __builtin_sqrt(1.0 - u * u);
         double sp, cp;
         rtm::sincosd(phi, &sp, &cp);
-        d3 v = dmk(sr * cp, sr * sp, u);
-        return flat ? v : rotate3(v, n, cost, sint);
+        const d3 v = dmk(sr * cp, sr * sp, u);
+        nd = flat ? v : rotate3(v, n, cost, sint);
+        if (!glossy || ddot(nd, normal) >= 0.0) break;
+        if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); break; }
     }
+    return nd;
 }
 
 // get_refraction_ray, main.cpp:107-122, with Line::reflect / Line::refract, geometry.cpp:78-92
@@ -316,7 +315,8 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax) {
     const float E0 = 24.0f * F32_U * S * S;
     r.a = make_float4(-fx, -fy, -fz, (float)od);
     const double thr = o2 - (double)E0 - (double)Eh * Eh * (1.0 + 1.0 / (double)BROAD_DELTA);
-    const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U);     // rounded down
+    // rounded down, and strictly below: the pipeline keeps a record iff thr - s is negative
+    const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U) - 1e-30f;
     r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);
     const float bc = (float)(o2 - (double)E0) - __builtin_fabsf((float)o2) * (4.0f * F32_U);
     r.c = make_float4(Eh * 1.00001f, bc, 0.0f, 0.0f);
@@ -443,42 +443,46 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
         fst.set(s.nverts - 1, 2, dc[2] * dd + sc[2] * sp);
     }
 
+    // how the segment ends; every terminating case funnels into ONE end_path call below so that the lanes
+    // of a wave that end their paths for different reasons share its instructions
+    bool term = false;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (is_light) {                                                                    // main.cpp:132-135
-        double c0 = m->ref[0], c1 = m->ref[1], c2 = m->ref[2];
+        c0 = m->ref[0]; c1 = m->ref[1]; c2 = m->ref[2];
         for (int k = s.nverts - 1; k >= 0; k--) {
             c0 = c0 * fst.get(k, 0); c1 = c1 * fst.get(k, 1); c2 = c2 * fst.get(k, 2);
         }
-        return end_path(s, c0, c1, c2, item, item_rays, kp);
-    }
-    if (dead_end) {
+        term = true;
+    } else if (dead_end) {
         for (int k = 0; k < kp.light_draws; k++) rng_next(s.rng);                      // rand_point of the first light
-        return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);
-    }
-    if (s.nverts >= kp.max_verts) {
+        term = true;
+    } else if (s.nverts >= kp.max_verts) {
         atomicOr(&kp.ctrl[1], ERR_STACK);
-        return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);
+        term = true;
+    } else {
+        d3 fwd;
+        int change = 1;
+        double n2 = 1.0;
+        bool reflect = false;
+        const double rindex = m->rindex;
+        if (__builtin_fabs(rindex - s.n_cur) < 0.0001) {                               // leaving, main.cpp:158-161
+            fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
+            change = 0;
+        } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                   // main.cpp:164-167
+            fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1]);
+            reflect = true;
+        } else {                                                                       // main.cpp:168-171
+            fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
+            n2 = rindex;
+        }
+        s.pv_n = normal;
+        s.pv_r = dneg(reflect_dir(s.d, normal));
+        s.pv_mat = mi;
+        s.flags = reflect ? (s.flags | FL_PV_REFLECT) : (s.flags & ~FL_PV_REFLECT);
+        s.nverts++;
+        s.o = h.p; s.d = fwd; s.remaining -= change; s.n_cur = n2;
     }
-    d3 fwd;
-    int change = 1;
-    double n2 = 1.0;
-    bool reflect = false;
-    const double rindex = m->rindex;
-    if (__builtin_fabs(rindex - s.n_cur) < 0.0001) {                                   // leaving, main.cpp:158-161
-        fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
-        change = 0;
-    } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                       // main.cpp:164-167
-        fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1]);
-        reflect = true;
-    } else {                                                                           // main.cpp:168-171
-        fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
-        n2 = rindex;
-    }
-    s.pv_n = normal;
-    s.pv_r = dneg(reflect_dir(s.d, normal));
-    s.pv_mat = mi;
-    s.flags = reflect ? (s.flags | FL_PV_REFLECT) : (s.flags & ~FL_PV_REFLECT);
-    s.nverts++;
-    s.o = h.p; s.d = fwd; s.remaining -= change; s.n_cur = n2;
+    if (term) return end_path(s, c0, c1, c2, item, item_rays, kp);
     return true;
 }
 
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
         h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
         int ncand = 0;
         auto narrow = [&]() {
-            for (int k = 0; k < ncand; k++) narrow_one(cand[k], s.o, s.d, kp, h);
+            for (int k = 0; k < ncand; k++) if (cand[k] < kp.n_prims) narrow_one(cand[k], s.o, s.d, kp, h);
             ncand_total += (unsigned)ncand;
             ncand = 0;
         };
@@ -641,7 +645,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 //                                   next queue by ballot rank (one atomic per wave)
 // until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
 // small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
-constexpr int WF_CAND_CAP = 16;        // candidate slots per queued ray; overflow falls back to a full exact scan
+constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS windows are multiples of it
+constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
+constexpr int WF_CAND_CAP = 16;        // non-zero mask words kept per ray; beyond that the ray gets a full exact scan
 constexpr unsigned WF_OVERFLOW = 0xffffffffu;
 enum { SI_RNG = 0, SI_PX, SI_PY, SI_SAMPLE, SI_REMAINING, SI_NVERTS, SI_PVMAT, SI_FLAGS, SI_COUNT };
 enum { SD_NCUR = 0, SD_ACC = 1, SD_O = 4, SD_D = 7, SD_PVN = 10, SD_PVR = 13, SD_COUNT = 16 };
@@ -657,8 +663,11 @@ struct WfParams {
     unsigned* queue[2];        // slot ids of the live rays
     unsigned* counts;          // counts[i] = live rays entering iteration i
     float4* rec[3];            // ray records by queue position
-    unsigned* cand;            // [slots][WF_CAND_CAP] by queue position
-    unsigned* cand_cnt;        // [slots]
+    uint2* cand;               // [slots][WF_CAND_CAP] by queue position: (word index j, keep mask of records 32j..32j+31,
+                               // bit 31-k = record 32j+k), only the non-zero words, ascending j
+    unsigned* cand_cnt;        // [slots] entries used; WF_OVERFLOW = more than WF_CAND_CAP non-zero words
+    double* hit_p;             // [3][slots] by queue position: closest hit point of the queued ray
+    int* hit_idx;              // [slots] by queue position: file index of the solid hit, -1 = none
 };
 
 DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
@@ -710,8 +719,22 @@ __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
     }
 }
 
-// Two rays per lane: one LDS broadcast read feeds 16 VALU instructions, which keeps the LDS pipe
-// (4 cycles per ds_read_b128 per wave) well below the VALU time of the four SIMDs it serves.
+// sign bit of (thr - s) shifted into a 32-record mask: kept iff s > thr.  A NaN s (NaN ray) comes out
+// negative, i.e. kept -- the exact test then decides; padding records give s = -inf, never kept.
+DEV unsigned push_bit(unsigned acc, float thr, float s) {
+    return __builtin_amdgcn_alignbit(acc, __float_as_uint(thr - s), 31u);
+}
+DEV float broad_s2(const float4 rec, const float4 ra, const float4 rb) {
+    const float hb = __builtin_fmaf(ra.z, rec.z, __builtin_fmaf(ra.y, rec.y, __builtin_fmaf(ra.x, rec.x, ra.w)));
+    const float nq = __builtin_fmaf(rb.z, rec.z, __builtin_fmaf(rb.y, rec.y, __builtin_fmaf(rb.x, rec.x, rec.w)));
+    return __builtin_fmaf(hb, hb, nq);
+}
+
+// The hot kernel.  Every lane carries two rays; the records are read from LDS at a wave-uniform
+// address (broadcast), so one ds_read_b128 feeds 18 VALU instructions: 2 x (3 fma + 3 fma + fma + sub +
+// alignbit).  There is no branch inside a group of 32 records; each group ends with one coalesced
+// store of the 32-bit keep mask per ray.  Workgroups are persistent over ray batches, the LDS window is
+// staged once per window.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
     extern __shared__ float4 lds[];
@@ -730,47 +753,39 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
             for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
         }
         __syncthreads();
+        const int word0 = ch.first_index / BROAD_GROUP;
         for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
             const unsigned pA = batch * per_block + threadIdx.x, pB = pA + BLOCK;
             const bool vA = pA < count, vB = pB < count;
-            // dead lanes carry NaN constants: every comparison is false
+            // idle lanes carry NaN constants: no bit is ever set for them
             const float4 aA = vA ? w.rec[0][pA] : nan4, bA = vA ? w.rec[1][pA] : nan4;
             const float4 aB = vB ? w.rec[0][pB] : nan4, bB = vB ? w.rec[1][pB] : nan4;
+            const float thrA = bA.w, thrB = bB.w;
             unsigned nA = 0, nB = 0;
             if (c > 0) { if (vA) nA = w.cand_cnt[pA]; if (vB) nB = w.cand_cnt[pB]; }
-            const float thrA = bA.w, thrB = bB.w;
-            auto keep = [&](unsigned pos, unsigned& n, float hb, float nq, int idx) {
-                if (n == WF_OVERFLOW) return;
-                const float4 rc = w.rec[2][pos];
-                if (broad_behind(hb, nq, rc)) return;
-                if (n >= (unsigned)WF_CAND_CAP) { n = WF_OVERFLOW; return; }
-                w.cand[(size_t)pos * WF_CAND_CAP + n] = (unsigned)idx;
-                n++;
-            };
-            float4 r0 = lds[0], r1 = lds[1], r2 = lds[2], r3 = lds[3];
-            for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
-                // prefetch the next group while this one is evaluated (the last prefetch re-reads the last group)
-                const int nx = (i + BROAD_UNROLL < ch.count) ? i + BROAD_UNROLL : i;
-                const float4 n0 = lds[nx], n1 = lds[nx + 1], n2 = lds[nx + 2], n3 = lds[nx + 3];
-                float hA0, hA1, hA2, hA3, qA0, qA1, qA2, qA3, hB0, hB1, hB2, hB3, qB0, qB1, qB2, qB3;
-                const float sA0 = broad_s(r0, aA, bA, hA0, qA0), sB0 = broad_s(r0, aB, bB, hB0, qB0);
-                const float sA1 = broad_s(r1, aA, bA, hA1, qA1), sB1 = broad_s(r1, aB, bB, hB1, qB1);
-                const float sA2 = broad_s(r2, aA, bA, hA2, qA2), sB2 = broad_s(r2, aB, bB, hB2, qB2);
-                const float sA3 = broad_s(r3, aA, bA, hA3, qA3), sB3 = broad_s(r3, aB, bB, hB3, qB3);
-                const bool fA = (sA0 >= thrA) | (sA1 >= thrA) | (sA2 >= thrA) | (sA3 >= thrA);
-                const bool fB = (sB0 >= thrB) | (sB1 >= thrB) | (sB2 >= thrB) | (sB3 >= thrB);
-                if (fA | fB) {
-                    const int base = ch.first_index + i;
-                    if (sA0 >= thrA) keep(pA, nA, hA0, qA0, base);
-                    if (sA1 >= thrA) keep(pA, nA, hA1, qA1, base + 1);
-                    if (sA2 >= thrA) keep(pA, nA, hA2, qA2, base + 2);
-                    if (sA3 >= thrA) keep(pA, nA, hA3, qA3, base + 3);
-                    if (sB0 >= thrB) keep(pB, nB, hB0, qB0, base);
-                    if (sB1 >= thrB) keep(pB, nB, hB1, qB1, base + 1);
-                    if (sB2 >= thrB) keep(pB, nB, hB2, qB2, base + 2);
-                    if (sB3 >= thrB) keep(pB, nB, hB3, qB3, base + 3);
+            uint2* outA = w.cand + (size_t)pA * WF_CAND_CAP;
+            uint2* outB = w.cand + (size_t)pB * WF_CAND_CAP;
+            for (int g = 0; g < ch.count; g += BROAD_GROUP) {
+                unsigned mA = 0, mB = 0;
+#pragma unroll 1
+                for (int k0 = 0; k0 < BROAD_GROUP; k0 += BROAD_INNER) {
+                    float4 r[BROAD_INNER];
+#pragma unroll
+                    for (int k = 0; k < BROAD_INNER; k++) r[k] = lds[g + k0 + k];
+#pragma unroll
+                    for (int k = 0; k < BROAD_INNER; k++) {
+                        mA = push_bit(mA, thrA, broad_s2(r[k], aA, bA));
+                        mB = push_bit(mB, thrB, broad_s2(r[k], aB, bB));
+                    }
                 }
-                r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+                // append the non-zero words to the ray's list (idle lanes never store)
+                const unsigned j = (unsigned)(word0 + g / BROAD_GROUP);
+                if (mA != 0u && vA && nA != WF_OVERFLOW) {
+                    if (nA < (unsigned)WF_CAND_CAP) { outA[nA] = make_uint2(j, mA); nA++; } else nA = WF_OVERFLOW;
+                }
+                if (mB != 0u && vB && nB != WF_OVERFLOW) {
+                    if (nB < (unsigned)WF_CAND_CAP) { outB[nB] = make_uint2(j, mB); nB++; } else nB = WF_OVERFLOW;
+                }
             }
             if (vA) w.cand_cnt[pA] = nA;
             if (vB) w.cand_cnt[pB] = nB;
@@ -778,13 +793,59 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
     }
 }
 
+// narrow phase: the kept records of every queued ray, in file order, through the reference's exact test
+__global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
+    const unsigned count = w.counts[w.iter];
+    const int lane = threadIdx.x & 63;
+    const int qi = w.iter & 1;
+    unsigned long long ncand_total = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const size_t n_slots = w.slots;
+    for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
+        const unsigned slot = w.queue[qi][pos];
+        const double* sd = w.sd + slot;
+        const d3 o = dmk(sd[(SD_O + 0) * n_slots], sd[(SD_O + 1) * n_slots], sd[(SD_O + 2) * n_slots]);
+        const d3 d = dmk(sd[(SD_D + 0) * n_slots], sd[(SD_D + 1) * n_slots], sd[(SD_D + 2) * n_slots]);
+        Hit h;
+        h.len = __builtin_inf(); h.idx = -1;
+        h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+        const unsigned n = w.cand_cnt[pos];
+        if (n == WF_OVERFLOW) {
+            // more non-zero words than list entries: exact test against the whole list, file order
+            for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
+            ncand_total += (unsigned)w.kp.n_prims;
+        } else {
+            const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
+            for (unsigned e = 0; e < n; e++) {
+                const uint2 ent = cl[e];
+                unsigned m = ent.y;
+                ncand_total += (unsigned)__popc(m);
+                while (m) {
+                    const int k = __clz((int)m);
+                    m &= ~(0x80000000u >> k);
+                    const int idx = (int)ent.x * BROAD_GROUP + k;
+                    // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
+                    // included: indices past the list are never dereferenced
+                    if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+                }
+            }
+        }
+        w.hit_idx[pos] = h.idx;
+        w.hit_p[pos] = h.p.x; w.hit_p[n_slots + pos] = h.p.y; w.hit_p[2 * n_slots + pos] = h.p.z;
+    }
+    unsigned long long cn = ncand_total;
+    for (int off = 32; off > 0; off >>= 1) cn += __shfl_down(cn, off, 64);
+    if (lane == 0 && cn) atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
+}
+
+// one segment of add_to_path per queued ray; survivors are packed into the next queue
 __global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
     const unsigned count = w.counts[w.iter];
     const int lane = threadIdx.x & 63;
     const int qi = w.iter & 1, qo = qi ^ 1;
     unsigned nrays = 0;
-    unsigned long long ncand_total = 0;
     const unsigned stride = gridDim.x * blockDim.x;
+    const size_t n_slots = w.slots;
     // every lane of a wave runs the same number of trips so that the ballot below sees whole waves
     const unsigned trips = (count + stride - 1) / stride;
     for (unsigned t = 0; t < trips; t++) {
@@ -796,18 +857,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
             slot = w.queue[qi][pos];
             load_state(w, slot, s);
             Hit h;
-            h.len = __builtin_inf(); h.idx = -1;
-            h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-            const unsigned n = w.cand_cnt[pos];
-            if (n == WF_OVERFLOW) {
-                // more candidates than slots: exact test against the whole list, file order
-                for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, s.o, s.d, w.kp, h);
-                ncand_total += (unsigned)w.kp.n_prims;
-            } else {
-                const unsigned* cl = w.cand + (size_t)pos * WF_CAND_CAP;
-                for (unsigned k = 0; k < n; k++) narrow_one((int)cl[k], s.o, s.d, w.kp, h);
-                ncand_total += n;
-            }
+            h.len = 0.0;
+            h.idx = w.hit_idx[pos];
+            h.p = dmk(w.hit_p[pos], w.hit_p[n_slots + pos], w.hit_p[2 * n_slots + pos]);
             nrays++;
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
@@ -823,12 +875,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
             if (alive) emit_ray(w, base + rank, slot, s, qo);
         }
     }
-    unsigned long long r = nrays, cn = ncand_total;
-    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
-    if (lane == 0 && r) {
-        atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
-        atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
-    }
+    unsigned long long r = nrays;
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+    if (lane == 0 && r) atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
 }
 
 // fn: 0 sin, 1 cos, 2 acos, 3 pow, 4 x/y, 5 sqrt(x), 6 next RNG state of (uint64)x bits
@@ -886,6 +935,7 @@ struct rt_context {
     void* d_mats = nullptr;
     int nchunks = 0;
     int max_chunk_records = 0;
+    int n_records_padded = 0;  // records incl. the NaN padding of every LDS window
     float cmax = 0;
     double T[3] = {0, 0, 0};
     unsigned* d_ctrl = nullptr;
@@ -896,7 +946,8 @@ struct rt_context {
     unsigned* wf_queue[2] = {nullptr, nullptr};
     unsigned* wf_counts = nullptr;
     float4* wf_rec[3] = {nullptr, nullptr, nullptr};
-    unsigned* wf_cand = nullptr; unsigned* wf_cand_cnt = nullptr;
+    uint2* wf_cand = nullptr; unsigned* wf_cand_cnt = nullptr;
+    double* wf_hit_p = nullptr; int* wf_hit_idx = nullptr;
     std::vector<hipEvent_t> broad_ev;   // pairs around every broad_kernel launch when timing_detail is on
     int broad_ev_used = 0;
     // scratch outputs of rt_render
@@ -938,9 +989,9 @@ void free_scene(rt_context* h) {
 void free_pipeline(rt_context* h) {
     hipFree(h->wf_si); hipFree(h->wf_sd); hipFree(h->wf_stack); hipFree(h->wf_queue[0]); hipFree(h->wf_queue[1]);
     hipFree(h->wf_counts); hipFree(h->wf_rec[0]); hipFree(h->wf_rec[1]); hipFree(h->wf_rec[2]);
-    hipFree(h->wf_cand); hipFree(h->wf_cand_cnt);
+    hipFree(h->wf_cand); hipFree(h->wf_cand_cnt); hipFree(h->wf_hit_p); hipFree(h->wf_hit_idx);
     h->wf_si = nullptr; h->wf_sd = nullptr; h->wf_stack = nullptr; h->wf_queue[0] = h->wf_queue[1] = nullptr;
-    h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = h->wf_rec[2] = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr;
+    h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = h->wf_rec[2] = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr; h->wf_hit_p = nullptr; h->wf_hit_idx = nullptr;
     h->wf_slots = 0; h->wf_verts = 0; h->wf_iters = 0;
 }
 
@@ -979,7 +1030,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.records = (const float4*)h->d_records;
     kp.chunks = (const ChunkDesc*)h->d_chunks;
     kp.prims = (const PrimD*)h->d_prims;
-    kp.verts = (const double*)h->d_verts;
+    kp.verts = (const FaceV*)h->d_verts;
     kp.mats = (const MatD*)h->d_mats;
     kp.ctrl = h->d_ctrl;
 }
@@ -1070,7 +1121,7 @@ int rt_set_option(rt_handle h, int key, int value) {
         case RT_OPT_WG_PER_CU: h->grid_mult = value > 0 ? value : 0; return RT_OK;
         case RT_OPT_CHUNK_RECORDS:   // takes effect at the next rt_upload_scene
             if (value < 64 || value > 9728) return fail(h, RT_ERR_ARG, "rt_set_option: LDS window must be 64..9728 records");
-            h->chunk_records = value / BROAD_UNROLL * BROAD_UNROLL; return RT_OK;
+            h->chunk_records = value / BROAD_GROUP * BROAD_GROUP; return RT_OK;
         case RT_OPT_MAX_SLOTS:
             if (value < 1) return fail(h, RT_ERR_ARG, "rt_set_option: max slots must be positive");
             h->max_slots = (size_t)value; return RT_OK;
@@ -1247,7 +1298,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         rec.insert(rec.end(), r4, r4 + 4);
         chunks.back().count++;
     }
-    // pad every chunk to the unroll width inside the record stream; NaN records are never kept
+    // pad every LDS window to whole mask words inside the record stream
     {
         std::vector<float> padded;
         int src = 0;
@@ -1255,27 +1306,53 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
             c.gofs = (int)(padded.size() / 4);
             padded.insert(padded.end(), rec.begin() + (size_t)src * 4, rec.begin() + (size_t)(src + c.count) * 4);
             src += c.count;
-            while (c.count % BROAD_UNROLL) { for (int k = 0; k < 4; k++) padded.push_back(NAN); c.count++; }
+            // padding records (0, 0, 0, -inf): s = hb^2 - inf = -inf for every finite ray, never kept
+            while (c.count % BROAD_GROUP) { padded.push_back(0.0f); padded.push_back(0.0f); padded.push_back(0.0f); padded.push_back(-INFINITY); c.count++; }
         }
         rec.swap(padded);
     }
-    if (chunks.empty()) { ChunkDesc c; c.gofs = 0; c.count = 0; c.first_index = 0; c.pad = 0; chunks.push_back(c); }
-    if (rec.empty()) rec.assign(4, NAN);
-    int maxrec = BROAD_UNROLL;
-    for (auto& c : chunks) if (c.count > maxrec) maxrec = c.count;
-    std::vector<double> vd((size_t)(n_verts > 0 ? n_verts : 1) * 3, 0.0);
-    if (n_verts) memcpy(vd.data(), verts, (size_t)n_verts * 3 * sizeof(double));
+    if (chunks.empty()) {   // empty scene: one window of padding keeps every loop and mask word well defined
+        ChunkDesc c; c.gofs = 0; c.count = BROAD_GROUP; c.first_index = 0; c.pad = 0;
+        chunks.push_back(c);
+        rec.clear();
+        for (int k = 0; k < BROAD_GROUP; k++) { rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(-INFINITY); }
+    }
+    int maxrec = BROAD_GROUP, totrec = 0;
+    for (auto& c : chunks) { if (c.count > maxrec) maxrec = c.count; totrec = c.first_index + c.count; }
+    h->n_records_padded = totrec;
+    // face vertex table: vertex, edge to the next vertex and to_next, per face, in the reference's operation order
+    // (geometry.cpp:163-164: (v_i - v_i+1).dot(v_i - v_i+2), Vector::dot accumulating from 0, left to right)
+    std::vector<FaceV> vd((size_t)(n_verts > 0 ? n_verts : 1));
+    memset(vd.data(), 0, vd.size() * sizeof(FaceV));
+    for (int i = 0; i < n_prims; i++) {
+        if (pd[i].kind != RT_KIND_FACE) continue;
+        const int nv = pd[i].vcnt, off = pd[i].voff;
+        for (int k = 0; k < nv; k++) {
+            const double* vi = verts + (size_t)(off + k) * 3;
+            const double* v1 = verts + (size_t)(off + (k + 1) % nv) * 3;
+            const double* v2 = verts + (size_t)(off + (k + 2) % nv) * 3;
+            FaceV& f = vd[(size_t)off + k];
+            double t = 0.0;
+            for (int a = 0; a < 3; a++) {
+                f.v[a] = vi[a];
+                f.e[a] = vi[a] - v1[a];
+                const double w = vi[a] - v2[a];
+                t = t + f.e[a] * w;
+            }
+            f.to_next = t;
+        }
+    }
 
     free_scene(h);
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));
-    HIP_TRY(h, hipMalloc(&h->d_verts, vd.size() * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_verts, vd.size() * sizeof(FaceV)));
     HIP_TRY(h, hipMalloc(&h->d_mats, md.size() * sizeof(MatD)));
     HIP_TRY(h, hipMemcpy(h->d_records, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_prims, pd.data(), pd.size() * sizeof(PrimD), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_verts, vd.data(), vd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_verts, vd.data(), vd.size() * sizeof(FaceV), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_mats, md.data(), md.size() * sizeof(MatD), hipMemcpyHostToDevice));
 
     h->width = W; h->height = H; h->spp = spp; h->depth = depth;
@@ -1355,8 +1432,10 @@ static int ensure_pipeline(rt_handle h, size_t slots, int verts, int iters) {
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_queue[q], slots * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_counts, ((size_t)iters + 2) * sizeof(unsigned)));
     for (int q = 0; q < 3; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_rec[q], slots * sizeof(float4)));
-    HIP_TRY(h, hipMalloc((void**)&h->wf_cand, slots * WF_CAND_CAP * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_cand, slots * WF_CAND_CAP * sizeof(uint2)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_cand_cnt, slots * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_hit_p, slots * 3 * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_hit_idx, slots * sizeof(int)));
     h->wf_slots = slots; h->wf_verts = verts; h->wf_iters = iters;
     return RT_OK;
 }
@@ -1385,6 +1464,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     w.counts = h->wf_counts;
     for (int q = 0; q < 3; q++) w.rec[q] = h->wf_rec[q];
     w.cand = h->wf_cand; w.cand_cnt = h->wf_cand_cnt;
+    w.hit_p = h->wf_hit_p; w.hit_idx = h->wf_hit_idx;
     unsigned bgrid = 1;
     hipError_t e;
     if (h->broad_block == 1024) e = broad_grid<1024>(h, &bgrid);
@@ -1417,6 +1497,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
             else e = launch_broad<512>(h, w, bgrid, st);
             if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
             if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
+            hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), 0, st, w);
             hipLaunchKernelGGL(shade_kernel, dim3(sgrid), dim3(256), 0, st, w);
         }
         e = hipGetLastError();

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #define RTM_FN __host__ __device__ __forceinline__
+#define RTM_BIG __host__ __device__ __attribute__((noinline))
 
 namespace rtm {
 
@@ -33,7 +34,7 @@ RTM_FN bool isnand(double x) { return (d2bits(x) & 0x7fffffffffffffffull) > 0x7f
 
 // sin and cos together: reduce by multiples of pi/2 (three-constant Cody-Waite), Taylor
 // polynomials on [-pi/4, pi/4], quadrant fix-up.  NaN for |x| >= 2^20.
-RTM_FN void sincosd(double x, double* sn, double* cs) {
+RTM_BIG void sincosd(double x, double* sn, double* cs) {
     if (!(absd(x) < 1048576.0)) { *sn = nand(); *cs = nand(); return; }
     double t = x * RTM_TWO_OVER_PI;
     int k = (int)(t + (t >= 0.0 ? 0.5 : -0.5));
@@ -82,7 +83,7 @@ RTM_FN double asin_poly(double x) {  // |x| <= 0.5: x + x^3 * (30-term Taylor ta
 
 // acos: pi/2 - asin(x) for |x| <= 1/2, else 2 asin(sqrt((1-|x|)/2)) reflected for x < 0.
 // |x| > 1 makes the sqrt argument negative, hence NaN.
-RTM_FN double acosd(double x) {
+RTM_BIG double acosd(double x) {
     double ax = absd(x);
     if (ax <= 0.5) return (RTM_PIO2 - asin_poly(x)) + RTM_PIO2_LOW;
     double z = (1.0 - ax) * 0.5;
@@ -133,7 +134,7 @@ RTM_FN double exp2d(double p) {
 // pow(x, y) = sign * 2^(y log2|x|) with pow's special cases: y == 0 or x == 1 give 1, NaN
 // propagates, a negative base needs an integral y (odd y keeps the sign), x == -1 gives +-1,
 // zero (and subnormal) and infinite bases go through log2 = -+inf.  A zero result is always +0.
-RTM_FN double powd(double x, double y) {
+RTM_BIG double powd(double x, double y) {
     if (y == 0.0) return 1.0;
     if (x == 1.0) return 1.0;
     if (isnand(x) || isnand(y)) return nand();
