@@ -1,0 +1,149 @@
+"""Host side of the boundary without a GPU: scene stream reader (Python mirror and C++ loader), expose,
+PNG writer, the C-ABI library's exports and its GPU-free entry points."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from raytracer_amd import api, scene as S, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "raytracer_amd")
+
+
+def _host_lib():
+    p = os.path.join(PKG, "librt_host.so")
+    if not os.path.exists(p):
+        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "../librt_host.so"])
+    return C.CDLL(p)
+
+
+def _dump_tables(path):
+    exe = os.path.join(PKG, "rt_main")
+    out = path + ".tables"
+    subprocess.check_call([exe, path, "/dev/null", "--no-render", "--dump-tables", out])
+    b = open(out, "rb").read()
+    npar, npr, nmt, nv = struct.unpack("<4i", b[:16])
+    off = 16
+    res = []
+    for n in (npar, npr * S.PR_STRIDE, nmt * S.MT_STRIDE, nv * 3):
+        res.append(np.frombuffer(b, dtype="<f8", count=n, offset=off)); off += 8 * n
+    return res
+
+
+def test_scene_json_tables(golden_dir):
+    sc = S.read_json_scene(os.path.join(golden_dir, "scene.json"))
+    assert sc.counts() == {"spheres": 2, "planes": 1, "faces": 5}
+    assert (sc.width, sc.height, sc.spp) == (400, 400, 10)
+    assert sc.mats.shape == (9, S.MT_STRIDE) and sc.verts.shape == (20, 3)
+    # gloss = spec/(diff+spec): mirror sphere 3/3, walls 0.9/(1.5+0.9)
+    assert sc.mats[int(sc.prims[6, S.PR_MAT0]), S.MT_GLOSS] == 1.0
+    assert sc.mats[int(sc.prims[2, S.PR_MAT0]), S.MT_GLOSS] == (0.3 + 0.3 + 0.3) / ((0.1 + 0.7 + 0.1) + (0.3 + 0.3 + 0.3))
+    assert sc.prims[5, S.PR_LIGHT] == 1.0 and sc.mats[int(sc.prims[5, S.PR_MAT0]), S.MT_LIGHT] == 1.0
+
+
+@pytest.mark.parametrize("name", ["scene.json", "small_room.scene.json", "small_mixed.scene.json"])
+def test_cpp_loader_equals_python_loader(golden_dir, name, tmp_path):
+    src = os.path.join(golden_dir, name)
+    dst = str(tmp_path / name)
+    open(dst, "w").write(open(src).read())
+    params, prims, mats, verts = _dump_tables(dst)
+    sc = S.read_json_scene(src)
+    assert np.array_equal(params.view(np.uint64), sc.params().view(np.uint64))
+    assert np.array_equal(prims.view(np.uint64), sc.prims.ravel().view(np.uint64))
+    assert np.array_equal(mats.view(np.uint64), sc.mats.ravel().view(np.uint64))
+    assert np.array_equal(verts.view(np.uint64), sc.verts.ravel().view(np.uint64))
+
+
+def test_scene_errors():
+    with pytest.raises(S.SceneError):
+        S.loads("")
+    with pytest.raises(S.SceneError):
+        S.loads('{"num_objs": 1}')
+    head = '{"num_threads":1,"num_objs":1,"exposure":1,"num_blurs":0,"paths_per_pixel":1,"max_ray_depth":1,"scale":1,"width":2,"height":2,"lens_radius":0,"focal_length":1}'
+    with pytest.raises(S.SceneError):
+        S.loads(head)                                        # object announced, none present
+    with pytest.raises(S.SceneError):
+        S.loads(head + '{"shape":"sphere","is_light":false,"center":[0,0,0]}')   # radius missing
+    with pytest.raises(S.SceneError):
+        S.loads(head + '{"shape": "sphere", ')               # malformed
+    sc = S.loads(head + '{"shape":"sphere","is_light":true,"center":[0,0,0],"radius":1,"color":[1,2,3]} {"ignored": 1}')
+    assert len(sc.prims) == 1 and sc.mats[0, S.MT_REF:S.MT_REF + 3].tolist() == [1, 2, 3]
+    exe = os.path.join(PKG, "rt_main")
+    r = subprocess.run([exe, "/nonexistent/scene.json", "/dev/null", "--no-render"], capture_output=True)
+    assert r.returncode == 1 and b"cannot open" in r.stderr
+
+
+def test_synth_is_deterministic_and_well_formed():
+    t1, s1 = synth.make("c3", width=64)
+    t2, s2 = synth.make("c3", width=64)
+    assert t1 == t2
+    assert s1.counts() == {"spheres": 1024, "planes": 1, "faces": 6}
+    _, s5 = synth.make("c5", width=64)
+    assert len(s5.prims) == 16384
+    # solids stay inside the room and do not overlap (sampled check on sphere pairs of neighbouring cells)
+    sp = s1.prims[s1.prims[:, S.PR_KIND] == S.KIND_SPHERE]
+    c, r = sp[:, S.PR_A:S.PR_A + 3], sp[:, S.PR_RADIUS]
+    assert (np.abs(c[:, 0]) + r < 20).all() and (c[:, 1] - r > -20).all() and (c[:, 1] + r < 20).all()
+    d = np.linalg.norm(c[:, None, :] - c[None, :, :], axis=-1) + np.eye(len(c)) * 1e9
+    assert (d > r[:, None] + r[None, :]).all()
+
+
+def test_expose_host_implementations_agree():
+    rng = np.random.default_rng(0)
+    rgb = rng.random((50, 70, 3)) ** 3 * 3
+    want, _ = po.expose(rgb, 1.0, 2)
+    assert np.array_equal(api.expose(rgb, 1.0, 2), want)
+    lib = _host_lib()
+    buf = np.ascontiguousarray(rgb).copy()
+    img = np.zeros((50, 70), dtype=np.int32)
+    lib.rt_host_expose(img.ctypes.data_as(C.POINTER(C.c_int)), buf.ctypes.data_as(C.POINTER(C.c_double)),
+                       70, 50, C.c_double(1.0), 2, 3)
+    assert np.array_equal(img, want)
+    want2, _ = po.expose(rgb * 0.2, 2.5, 0)
+    assert np.array_equal(api.expose(rgb * 0.2, 2.5, 0), want2)
+
+
+def test_write_image_round_trip(tmp_path):
+    from PIL import Image
+    lib = _host_lib()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 1 << 24, (37, 53)).astype(np.int32)
+    path = str(tmp_path / "o.png").encode()
+    assert lib.writeImage(C.c_char_p(path), 53, 37, img.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    got = np.array(Image.open(path.decode()).convert("RGB"))
+    assert np.array_equal(got, po.unpack_rgb(img))
+    assert lib.writeImage(C.c_char_p(b"/nonexistent/dir/o.png"), 53, 37, img.ctypes.data_as(C.POINTER(C.c_int))) == -1
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(rt_[a-z_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    lib = api.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_c_abi_entry_points_that_need_no_gpu():
+    lib = api.load_library()
+    assert api.rows_for_rank(2160, 8, 0, 8) == 272 and api.rows_for_rank(2160, 8, 7, 8) == 264
+    assert sum(api.rows_for_rank(1081, 8, r, 3) for r in range(3)) == 1081
+    assert api.rows_for_rank(10, 0, 0, 1) == -1 and api.rows_for_rank(10, 1, 2, 2) == -1
+    assert lib.rt_last_error(None) == b"null handle"
+    assert lib.rt_upload_scene(None, None, 0, None, 0, None, 0, None) == -1
+    assert lib.rt_finish(None, None) == -1
+    h = C.c_void_p()
+    rc = lib.rt_create(C.byref(h), 0)
+    if rc == 0:                       # a GPU is present: exercise the error paths that need a handle
+        assert lib.rt_render(h, None, None, None) == -3
+        assert lib.rt_set_option(h, 99, 0) == -1
+        lib.rt_destroy(h)
+    else:
+        assert rc == -6 and not h.value

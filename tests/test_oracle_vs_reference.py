@@ -1,0 +1,24 @@
+"""Pins the oracle to the compiled reference directly (only where oracle/_ref exists, i.e. in the build
+container: /root/reference does not travel).  Fresh scenes, several thread counts, bloom on and off."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from raytracer_amd import synth
+
+pytestmark = pytest.mark.skipif(not po.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("cfg,width,threads,blurs,kw", [
+    ("c2", 200, 3, 1, {}),
+    ("c3", 128, 5, 0, dict(lattice=(6, 4, 4))),
+    ("c5", 72, 8, 0, dict(spp=2)),
+])
+def test_oracle_equals_reference_binary(cfg, width, threads, blurs, kw):
+    text, sc = synth.make(cfg, width=width, num_threads=threads, num_blurs=blurs, seed=99, **kw)
+    ref = po.run_reference(text, num_threads=threads, num_blurs=blurs)
+    o = po.render(sc, policy=po.POLICY_REF, rng_mode=po.RNG_STREAM)
+    assert np.array_equal(ref["rays"], o["rays"])
+    assert np.array_equal(ref["rgb"].view(np.uint64), o["rgb"].view(np.uint64))
+    img, _ = po.expose(o["rgb"], sc.header["exposure"], blurs)
+    assert np.array_equal(img, ref["img"])
