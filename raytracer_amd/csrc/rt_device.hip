@@ -102,6 +102,10 @@ struct KParams {
     const PrimD* prims;
     const FaceV* verts;
     const MatD* mats;
+    const double* always;    // solids every ray must test exactly (unbounded or very large bounding sphere): per solid
+                             // ALW_HEAD doubles (kind, file index, vertex count, -, point[3], radius, normal[3], -) and
+                             // 8 doubles per face vertex (FaceV); their broad-phase records are padding
+    int n_always, always_doubles;
     double* rgb;
     int* hit_ids;
     unsigned long long* stream_rays;
@@ -162,11 +166,13 @@ struct Hit {
     d3 p;
 };
 
-// get_intersection's acceptance, main.cpp:37
+// get_intersection's acceptance, main.cpp:37: scanning in file order and taking a candidate iff its point is
+// valid and strictly nearer selects the smallest (distance, file index) pair.  Written as that pair
+// comparison, the selection no longer depends on the order in which candidates are examined.
 DEV void consider(d3 p, int idx, d3 o, Hit& h) {
     if (!dvalid(p)) return;
     double len = dlen(dsub(p, o));
-    if (h.len > len) { h.len = len; h.idx = idx; h.p = p; }
+    if (h.len > len || (h.len == len && idx < h.idx)) { h.len = len; h.idx = idx; h.p = p; }
 }
 
 // Sphere::intersect, geometry.cpp:129-138
@@ -497,6 +503,37 @@ DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) {
     consider(p0, idx, o, h);
 }
 
+// exact test of every "always" solid, read from `tab` (LDS or global) at wave-uniform addresses
+constexpr int ALW_HEAD = 12;
+DEV void narrow_always(const double* tab, int n_always, d3 o, d3 d, Hit& h) {
+    int off = 0;
+    for (int a = 0; a < n_always; a++) {
+        const double* r = tab + off;
+        const int kind = __builtin_amdgcn_readfirstlane((int)r[0]);
+        const int idx = __builtin_amdgcn_readfirstlane((int)r[1]);
+        const int nv = __builtin_amdgcn_readfirstlane((int)r[2]);
+        d3 p0;
+        if (kind == RT_KIND_SPHERE) {
+            PrimD s;
+            s.a[0] = r[4]; s.a[1] = r[5]; s.a[2] = r[6]; s.radius = r[7];
+            p0 = sphere_point(s, o, d);
+        } else {
+            p0 = plane_point(dmk(r[4], r[5], r[6]), dmk(r[8], r[9], r[10]), o, d);
+            if (kind == RT_KIND_FACE && !dnan(p0.x)) {
+                bool miss = false;
+                for (int i = 0; i < nv; i++) {
+                    const double* v = r + ALW_HEAD + 8 * i;
+                    double to_p = ddot(dmk(v[3], v[4], v[5]), dsub(dmk(v[0], v[1], v[2]), p0));
+                    if (to_p * v[6] < 0.0) miss = true;
+                }
+                if (miss) p0 = dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+            }
+        }
+        consider(p0, idx, o, h);
+        off += ALW_HEAD + 8 * nv;
+    }
+}
+
 DEV void map_item_to_pixel(unsigned item, const KParams& kp, int& px, int& py) {
     const int lr = (int)(item / (unsigned)kp.width);
     px = (int)(item - (unsigned)lr * (unsigned)kp.width);
@@ -621,6 +658,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
         }
 
         if (alive) {
+            narrow_always(kp.always, kp.n_always, s.o, s.d, h);
+            ncand_total += (unsigned)kp.n_always;
             narrow();
             nrays++;
             item_rays++;
@@ -795,7 +834,11 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
 
 // narrow phase: the kept records of every queued ray, in file order, through the reference's exact test
 __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
+    extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
+    if (count == 0) return;
+    for (int i = threadIdx.x; i < w.kp.always_doubles; i += 256) alw[i] = w.kp.always[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int qi = w.iter & 1;
     unsigned long long ncand_total = 0;
@@ -811,10 +854,12 @@ __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
         h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
         const unsigned n = w.cand_cnt[pos];
         if (n == WF_OVERFLOW) {
-            // more non-zero words than list entries: exact test against the whole list, file order
+            // more non-zero words than list entries: exact test against the whole list
             for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
             ncand_total += (unsigned)w.kp.n_prims;
         } else {
+            narrow_always(alw, w.kp.n_always, o, d, h);
+            ncand_total += (unsigned)w.kp.n_always;
             const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
             for (unsigned e = 0; e < n; e++) {
                 const uint2 ent = cl[e];
@@ -933,6 +978,7 @@ struct rt_context {
     void* d_prims = nullptr;
     void* d_verts = nullptr;
     void* d_mats = nullptr;
+    void* d_always = nullptr; int n_always = 0, always_doubles = 0;
     int nchunks = 0;
     int max_chunk_records = 0;
     int n_records_padded = 0;  // records incl. the NaN padding of every LDS window
@@ -981,8 +1027,8 @@ int fail(rt_context* h, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(rt_context* h) {
-    hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats);
-    h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = nullptr;
+    hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
+    h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = h->d_always = nullptr;
     h->have_scene = false;
 }
 
@@ -1032,6 +1078,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.prims = (const PrimD*)h->d_prims;
     kp.verts = (const FaceV*)h->d_verts;
     kp.mats = (const MatD*)h->d_mats;
+    kp.always = (const double*)h->d_always; kp.n_always = h->n_always; kp.always_doubles = h->always_doubles;
     kp.ctrl = h->d_ctrl;
 }
 
@@ -1277,6 +1324,23 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     if (lo[0] <= hi[0]) for (int k = 0; k < 3; k++) T[k] = 0.5 * (lo[k] + hi[k]);
     double cmax = 0;
 
+    // ---- "always" solids: unbounded ones and those whose bounding sphere is a sizeable part of the scene (room walls,
+    // floor, ceiling).  Nearly every ray would keep them, so they skip the broad phase: the narrow phase tests them for
+    // every ray from a small table (LDS), and their records become padding.  Any choice is correct; this one is for speed.
+    std::vector<char> always((size_t)n_prims + 1, 0);
+    {
+        double diag = 0;
+        if (lo[0] <= hi[0]) for (int k = 0; k < 3; k++) diag += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+        const double big = 0.125 * sqrt(diag);      // radius >= a quarter of the scene's half-diagonal
+        int cnt = 0, doubles = 0;
+        for (int i = 0; i < n_prims; i++) {
+            if (!(br[i] < 0 || br[i] >= big)) continue;
+            const int need = ALW_HEAD + 8 * (pd[i].kind == RT_KIND_FACE ? pd[i].vcnt : 0);
+            if (cnt >= 64 || doubles + need > 4096) continue;   // over budget: stays an ordinary record
+            always[i] = 1; cnt++; doubles += need;
+        }
+    }
+
     // ---- broad-phase records in file order, chunked to the LDS window, padded with NaN records
     std::vector<float> rec;
     std::vector<ChunkDesc> chunks;
@@ -1287,7 +1351,9 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
             chunks.push_back(c);
         }
         float r4[4];
-        if (br[i] < 0) {
+        if (always[i]) {
+            r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = -INFINITY;       // tested for every ray by the narrow phase: never kept here
+        } else if (br[i] < 0) {
             r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = INFINITY;        // unbounded: always kept, never "behind"
         } else {
             double c[3];
@@ -1343,7 +1409,29 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         }
     }
 
+    // the table of the "always" solids
+    std::vector<double> alw;
+    int n_always = 0;
+    for (int i = 0; i < n_prims; i++) {
+        if (!always[i]) continue;
+        const int nv = pd[i].kind == RT_KIND_FACE ? pd[i].vcnt : 0;
+        const double head[ALW_HEAD] = {(double)pd[i].kind, (double)i, (double)nv, 0.0, pd[i].a[0], pd[i].a[1], pd[i].a[2],
+                                       pd[i].radius, pd[i].n[0], pd[i].n[1], pd[i].n[2], 0.0};
+        alw.insert(alw.end(), head, head + ALW_HEAD);
+        for (int k = 0; k < nv; k++) {
+            const FaceV& f = vd[(size_t)pd[i].voff + k];
+            const double v8[8] = {f.v[0], f.v[1], f.v[2], f.e[0], f.e[1], f.e[2], f.to_next, 0.0};
+            alw.insert(alw.end(), v8, v8 + 8);
+        }
+        n_always++;
+    }
+    const int always_doubles = (int)alw.size();
+    if (alw.empty()) alw.push_back(0.0);
+
     free_scene(h);
+    HIP_TRY(h, hipMalloc(&h->d_always, alw.size() * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->n_always = n_always; h->always_doubles = always_doubles;
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));
@@ -1497,7 +1585,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
             else e = launch_broad<512>(h, w, bgrid, st);
             if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
             if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
-            hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), 0, st, w);
+            hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
             hipLaunchKernelGGL(shade_kernel, dim3(sgrid), dim3(256), 0, st, w);
         }
         e = hipGetLastError();
