@@ -353,6 +353,8 @@ struct PathState {
     double acc0, acc1, acc2;
     d3 o, d;                // current ray; o is also the previous vertex's point once nverts > 0
     d3 pv_n, pv_r;          // previous vertex: normal, mirror direction
+    double* acc_mem;        // pipeline: the pixel's radiance sum lives in memory (element c at acc_mem[c*acc_stride])
+    size_t acc_stride;      //           and is touched only when a path ends; null: kept in acc0..2
 };
 
 // the stack of per-vertex throughput factors: element (k, c) lives at base[(3k + c) * stride]
@@ -389,14 +391,17 @@ DEV void begin_pixel(PathState& s, unsigned item, const KParams& kp) {
     s.out_index = kp.stream_mode ? (unsigned)(s.py * kp.width + s.px) : item;
     s.sample = 0;
     s.acc0 = s.acc1 = s.acc2 = 0.0;
+    if (s.acc_mem && kp.spp > 1) { s.acc_mem[0] = 0.0; s.acc_mem[s.acc_stride] = 0.0; s.acc_mem[2 * s.acc_stride] = 0.0; }
     start_path(s, kp);
 }
 
 // a path ended with radiance (c0,c1,c2): main.cpp:271-275.  Returns false when the lane's item is finished.
 DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, unsigned long long item_rays, const KParams& kp) {
+    if (s.acc_mem && kp.spp > 1) { s.acc0 = s.acc_mem[0]; s.acc1 = s.acc_mem[s.acc_stride]; s.acc2 = s.acc_mem[2 * s.acc_stride]; }
     s.acc0 = s.acc0 + c0; s.acc1 = s.acc1 + c1; s.acc2 = s.acc2 + c2;
     s.sample++;
     if (s.sample < kp.spp) {
+        if (s.acc_mem) { s.acc_mem[0] = s.acc0; s.acc_mem[s.acc_stride] = s.acc1; s.acc_mem[2 * s.acc_stride] = s.acc2; }
         start_path(s, kp);
         return true;
     }
@@ -557,6 +562,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
     s.rng = 1; s.px = s.py = 0; s.sample = 0; s.remaining = 0; s.nverts = 0; s.pv_mat = 0; s.flags = 0; s.out_index = 0;
     s.n_cur = 1.0; s.acc0 = s.acc1 = s.acc2 = 0.0;
     s.o = dmk(0, 0, 0); s.d = dmk(0, 0, 1); s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
+    s.acc_mem = nullptr; s.acc_stride = 0;
     unsigned nrays = 0, ncand_total = 0;
     unsigned long long item_rays = 0;
     double fst_mem[RT_MAXV * 3];
@@ -688,8 +694,12 @@ constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS w
 constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
 constexpr int WF_CAND_CAP = 16;        // non-zero mask words kept per ray; beyond that the ray gets a full exact scan
 constexpr unsigned WF_OVERFLOW = 0xffffffffu;
-enum { SI_RNG = 0, SI_PX, SI_PY, SI_SAMPLE, SI_REMAINING, SI_NVERTS, SI_PVMAT, SI_FLAGS, SI_COUNT };
-enum { SD_NCUR = 0, SD_ACC = 1, SD_O = 4, SD_D = 7, SD_PVN = 10, SD_PVR = 13, SD_COUNT = 16 };
+// per-slot state kept between rounds: 4 ints + 12 doubles (+ 3 doubles of radiance sum, touched at path ends only).
+// Not stored: pixel coordinates (a function of the slot), the current refraction index (1, or the index of the
+// previous vertex's material when the path is inside a solid: a flag).
+enum { SI_RNG = 0, SI_SAMPLE, SI_PACK, SI_PVMAT, SI_COUNT };     // PACK = remaining (signed 8) | nverts << 8 | flags << 16
+enum { SD_O = 0, SD_D = 3, SD_PVN = 6, SD_PVR = 9, SD_COUNT = 12 };
+enum { FL_INSIDE = 4 };
 
 struct WfParams {
     KParams kp;
@@ -698,10 +708,11 @@ struct WfParams {
     int iter;                  // iteration number: queue iter&1 is read, (iter+1)&1 written
     int* si;                   // [SI_COUNT][slots]
     double* sd;                // [SD_COUNT][slots]
+    double* acc;               // [3][slots] radiance sum of the slot's pixel (used when paths_per_pixel > 1)
     double* stack;             // [3*max_verts][slots]
     unsigned* queue[2];        // slot ids of the live rays
     unsigned* counts;          // counts[i] = live rays entering iteration i
-    float4* rec[3];            // ray records by queue position
+    float4* rec[2];            // ray records by queue position
     uint2* cand;               // [slots][WF_CAND_CAP] by queue position: (word index j, keep mask of records 32j..32j+31,
                                // bit 31-k = record 32j+k), only the non-zero words, ascending j
     unsigned* cand_cnt;        // [slots] entries used; WF_OVERFLOW = more than WF_CAND_CAP non-zero words
@@ -711,13 +722,19 @@ struct WfParams {
 
 DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
     const size_t n = w.slots;
-    s.rng = (unsigned)w.si[SI_RNG * n + slot]; s.px = w.si[SI_PX * n + slot]; s.py = w.si[SI_PY * n + slot];
-    s.sample = w.si[SI_SAMPLE * n + slot]; s.remaining = w.si[SI_REMAINING * n + slot]; s.nverts = w.si[SI_NVERTS * n + slot];
-    s.pv_mat = w.si[SI_PVMAT * n + slot]; s.flags = w.si[SI_FLAGS * n + slot];
+    s.rng = (unsigned)w.si[SI_RNG * n + slot];
+    s.sample = w.si[SI_SAMPLE * n + slot];
+    const int pk = w.si[SI_PACK * n + slot];
+    s.pv_mat = w.si[SI_PVMAT * n + slot];
+    s.remaining = (int)(signed char)(pk & 0xff);
+    s.nverts = (pk >> 8) & 0xff;
+    s.flags = (pk >> 16) & 0xff;
+    map_item_to_pixel(w.item_base + slot, w.kp, s.px, s.py);
     s.out_index = w.item_base + slot;
+    s.n_cur = (s.flags & FL_INSIDE) ? w.kp.mats[s.pv_mat].rindex : 1.0;
+    s.acc0 = s.acc1 = s.acc2 = 0.0;
+    s.acc_mem = w.acc + slot; s.acc_stride = n;
     const double* d = w.sd + slot;
-    s.n_cur = d[SD_NCUR * n];
-    s.acc0 = d[(SD_ACC + 0) * n]; s.acc1 = d[(SD_ACC + 1) * n]; s.acc2 = d[(SD_ACC + 2) * n];
     s.o = dmk(d[(SD_O + 0) * n], d[(SD_O + 1) * n], d[(SD_O + 2) * n]);
     s.d = dmk(d[(SD_D + 0) * n], d[(SD_D + 1) * n], d[(SD_D + 2) * n]);
     s.pv_n = dmk(d[(SD_PVN + 0) * n], d[(SD_PVN + 1) * n], d[(SD_PVN + 2) * n]);
@@ -726,12 +743,13 @@ DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
 
 DEV void store_state(const WfParams& w, unsigned slot, const PathState& s) {
     const size_t n = w.slots;
-    w.si[SI_RNG * n + slot] = (int)s.rng; w.si[SI_PX * n + slot] = s.px; w.si[SI_PY * n + slot] = s.py;
-    w.si[SI_SAMPLE * n + slot] = s.sample; w.si[SI_REMAINING * n + slot] = s.remaining; w.si[SI_NVERTS * n + slot] = s.nverts;
-    w.si[SI_PVMAT * n + slot] = s.pv_mat; w.si[SI_FLAGS * n + slot] = s.flags;
+    w.si[SI_RNG * n + slot] = (int)s.rng;
+    w.si[SI_SAMPLE * n + slot] = s.sample;
+    // the refraction index is 1 unless the last bounce entered a solid, and then it is that solid's (= pv_mat's) index
+    const int flags = (s.flags & (FL_FIRST_SEG | FL_PV_REFLECT)) | ((s.n_cur != 1.0) ? FL_INSIDE : 0);
+    w.si[SI_PACK * n + slot] = (s.remaining & 0xff) | ((s.nverts & 0xff) << 8) | (flags << 16);
+    w.si[SI_PVMAT * n + slot] = s.pv_mat;
     double* d = w.sd + slot;
-    d[SD_NCUR * n] = s.n_cur;
-    d[(SD_ACC + 0) * n] = s.acc0; d[(SD_ACC + 1) * n] = s.acc1; d[(SD_ACC + 2) * n] = s.acc2;
     d[(SD_O + 0) * n] = s.o.x; d[(SD_O + 1) * n] = s.o.y; d[(SD_O + 2) * n] = s.o.z;
     d[(SD_D + 0) * n] = s.d.x; d[(SD_D + 1) * n] = s.d.y; d[(SD_D + 2) * n] = s.d.z;
     d[(SD_PVN + 0) * n] = s.pv_n.x; d[(SD_PVN + 1) * n] = s.pv_n.y; d[(SD_PVN + 2) * n] = s.pv_n.z;
@@ -741,7 +759,7 @@ DEV void store_state(const WfParams& w, unsigned slot, const PathState& s) {
 DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathState& s, int q) {
     w.queue[q][pos] = slot;
     const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
-    w.rec[0][pos] = r.a; w.rec[1][pos] = r.b; w.rec[2][pos] = r.c;
+    w.rec[0][pos] = r.a; w.rec[1][pos] = r.b;
 }
 
 __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
@@ -752,6 +770,7 @@ __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
         map_item_to_pixel(item, w.kp, s.px, s.py);
         s.rng = pixel_seed((unsigned)(s.py * w.kp.width + s.px), w.kp.frame_seed);
         s.pv_mat = 0; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
+        s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
         begin_pixel(s, item, w.kp);
         store_state(w, slot, s);
         emit_ray(w, slot, slot, s, 0);
@@ -988,10 +1007,10 @@ struct rt_context {
     unsigned long long* d_stream_rays = nullptr; int stream_cap = 0;
     // pipeline state (per-pixel mode), sized for wf_slots pixel slots and wf_verts stack entries
     size_t wf_slots = 0; int wf_verts = 0; int wf_iters = 0;
-    int* wf_si = nullptr; double* wf_sd = nullptr; double* wf_stack = nullptr;
+    int* wf_si = nullptr; double* wf_sd = nullptr; double* wf_stack = nullptr; double* wf_acc = nullptr;
     unsigned* wf_queue[2] = {nullptr, nullptr};
     unsigned* wf_counts = nullptr;
-    float4* wf_rec[3] = {nullptr, nullptr, nullptr};
+    float4* wf_rec[2] = {nullptr, nullptr};
     uint2* wf_cand = nullptr; unsigned* wf_cand_cnt = nullptr;
     double* wf_hit_p = nullptr; int* wf_hit_idx = nullptr;
     std::vector<hipEvent_t> broad_ev;   // pairs around every broad_kernel launch when timing_detail is on
@@ -1034,10 +1053,10 @@ void free_scene(rt_context* h) {
 
 void free_pipeline(rt_context* h) {
     hipFree(h->wf_si); hipFree(h->wf_sd); hipFree(h->wf_stack); hipFree(h->wf_queue[0]); hipFree(h->wf_queue[1]);
-    hipFree(h->wf_counts); hipFree(h->wf_rec[0]); hipFree(h->wf_rec[1]); hipFree(h->wf_rec[2]);
+    hipFree(h->wf_counts); hipFree(h->wf_rec[0]); hipFree(h->wf_rec[1]); hipFree(h->wf_acc);
     hipFree(h->wf_cand); hipFree(h->wf_cand_cnt); hipFree(h->wf_hit_p); hipFree(h->wf_hit_idx);
     h->wf_si = nullptr; h->wf_sd = nullptr; h->wf_stack = nullptr; h->wf_queue[0] = h->wf_queue[1] = nullptr;
-    h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = h->wf_rec[2] = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr; h->wf_hit_p = nullptr; h->wf_hit_idx = nullptr;
+    h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = nullptr; h->wf_acc = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr; h->wf_hit_p = nullptr; h->wf_hit_idx = nullptr;
     h->wf_slots = 0; h->wf_verts = 0; h->wf_iters = 0;
 }
 
@@ -1519,7 +1538,8 @@ static int ensure_pipeline(rt_handle h, size_t slots, int verts, int iters) {
     HIP_TRY(h, hipMalloc((void**)&h->wf_stack, slots * (size_t)verts * 3 * sizeof(double)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_queue[q], slots * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_counts, ((size_t)iters + 2) * sizeof(unsigned)));
-    for (int q = 0; q < 3; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_rec[q], slots * sizeof(float4)));
+    for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_rec[q], slots * sizeof(float4)));
+    HIP_TRY(h, hipMalloc((void**)&h->wf_acc, slots * 3 * sizeof(double)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_cand, slots * WF_CAND_CAP * sizeof(uint2)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_cand_cnt, slots * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_hit_p, slots * 3 * sizeof(double)));
@@ -1550,7 +1570,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     w.si = h->wf_si; w.sd = h->wf_sd; w.stack = h->wf_stack;
     w.queue[0] = h->wf_queue[0]; w.queue[1] = h->wf_queue[1];
     w.counts = h->wf_counts;
-    for (int q = 0; q < 3; q++) w.rec[q] = h->wf_rec[q];
+    for (int q = 0; q < 2; q++) w.rec[q] = h->wf_rec[q];
+    w.acc = h->wf_acc;
     w.cand = h->wf_cand; w.cand_cnt = h->wf_cand_cnt;
     w.hit_p = h->wf_hit_p; w.hit_idx = h->wf_hit_idx;
     unsigned bgrid = 1;

@@ -34,8 +34,10 @@ RTM_FN bool isnand(double x) { return (d2bits(x) & 0x7fffffffffffffffull) > 0x7f
 
 // sin and cos together: reduce by multiples of pi/2 (three-constant Cody-Waite), Taylor
 // polynomials on [-pi/4, pi/4], quadrant fix-up.  NaN for |x| >= 2^20.
-RTM_BIG void sincosd(double x, double* sn, double* cs) {
-    if (!(absd(x) < 1048576.0)) { *sn = nand(); *cs = nand(); return; }
+struct SinCos { double s, c; };
+RTM_BIG SinCos sincos2(double x) {
+    SinCos out;
+    if (!(absd(x) < 1048576.0)) { out.s = nand(); out.c = nand(); return out; }
     double t = x * RTM_TWO_OVER_PI;
     int k = (int)(t + (t >= 0.0 ? 0.5 : -0.5));
     double kd = (double)k;
@@ -58,12 +60,14 @@ RTM_BIG void sincosd(double x, double* sn, double* cs) {
     double co = (q & 1) ? s : c;
     if (q == 2 || q == 3) so = -so;
     if (q == 1 || q == 2) co = -co;
-    *sn = so;
-    *cs = co;
+    out.s = so;
+    out.c = co;
+    return out;
 }
 
-RTM_FN double sind(double x) { double s, c; sincosd(x, &s, &c); return s; }
-RTM_FN double cosd(double x) { double s, c; sincosd(x, &s, &c); return c; }
+RTM_FN void sincosd(double x, double* sn, double* cs) { const SinCos r = sincos2(x); *sn = r.s; *cs = r.c; }
+RTM_FN double sind(double x) { return sincos2(x).s; }
+RTM_FN double cosd(double x) { return sincos2(x).c; }
 
 RTM_FN double asin_poly(double x) {  // |x| <= 0.5: x + x^3 * (30-term Taylor tail in x^2)
     double x2 = x * x;
