@@ -108,7 +108,8 @@ enum {
     RT_OPT_BROAD_BLOCK = 3,    /* workgroup size of broad_kernel: 256/512/1024                  */
     RT_OPT_WG_PER_CU = 4,      /* persistent workgroups per CU, 0 = occupancy query             */
     RT_OPT_CHUNK_RECORDS = 5,  /* LDS window in 16-byte records (next rt_upload_scene)          */
-    RT_OPT_MAX_SLOTS = 6       /* pixels whose path state is kept at once (memory cap)          */
+    RT_OPT_MAX_SLOTS = 6,      /* pixels whose path state is kept at once (memory cap)          */
+    RT_OPT_FUSE_NARROW = 7     /* 1: exact narrow phase inside shade_kernel (one launch less)   */
 };
 enum { RT_MODE_PIPELINE = 0, RT_MODE_SINGLE_KERNEL = 1 };
 

@@ -690,6 +690,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 //                                   next queue by ballot rank (one atomic per wave)
 // until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
 // small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 4
+#endif
 constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS windows are multiples of it
 constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
 constexpr int WF_CAND_CAP = 16;        // non-zero mask words kept per ray; beyond that the ray gets a full exact scan
@@ -851,7 +854,39 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
     }
 }
 
-// narrow phase: the kept records of every queued ray, in file order, through the reference's exact test
+// closest hit of the ray queued at `pos`: the always-tested solids (table `alw`, LDS) and the ray's kept records
+// through the reference's exact test
+DEV Hit find_hit(const WfParams& w, unsigned pos, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
+    Hit h;
+    h.len = __builtin_inf(); h.idx = -1;
+    h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+    const unsigned n = w.cand_cnt[pos];
+    if (n == WF_OVERFLOW) {
+        // more non-zero words than list entries: exact test against the whole list
+        for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
+        ncand_total += (unsigned)w.kp.n_prims;
+        return h;
+    }
+    narrow_always(alw, w.kp.n_always, o, d, h);
+    ncand_total += (unsigned)w.kp.n_always;
+    const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
+    for (unsigned e = 0; e < n; e++) {
+        const uint2 ent = cl[e];
+        unsigned m = ent.y;
+        ncand_total += (unsigned)__popc(m);
+        while (m) {
+            const int k = __clz((int)m);
+            m &= ~(0x80000000u >> k);
+            const int idx = (int)ent.x * BROAD_GROUP + k;
+            // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
+            // included: indices past the list are never dereferenced
+            if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+        }
+    }
+    return h;
+}
+
+// narrow phase as a kernel of its own (RT_OPT_FUSE_NARROW = 0)
 __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
     extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
@@ -868,32 +903,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
         const double* sd = w.sd + slot;
         const d3 o = dmk(sd[(SD_O + 0) * n_slots], sd[(SD_O + 1) * n_slots], sd[(SD_O + 2) * n_slots]);
         const d3 d = dmk(sd[(SD_D + 0) * n_slots], sd[(SD_D + 1) * n_slots], sd[(SD_D + 2) * n_slots]);
-        Hit h;
-        h.len = __builtin_inf(); h.idx = -1;
-        h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-        const unsigned n = w.cand_cnt[pos];
-        if (n == WF_OVERFLOW) {
-            // more non-zero words than list entries: exact test against the whole list
-            for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
-            ncand_total += (unsigned)w.kp.n_prims;
-        } else {
-            narrow_always(alw, w.kp.n_always, o, d, h);
-            ncand_total += (unsigned)w.kp.n_always;
-            const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
-            for (unsigned e = 0; e < n; e++) {
-                const uint2 ent = cl[e];
-                unsigned m = ent.y;
-                ncand_total += (unsigned)__popc(m);
-                while (m) {
-                    const int k = __clz((int)m);
-                    m &= ~(0x80000000u >> k);
-                    const int idx = (int)ent.x * BROAD_GROUP + k;
-                    // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
-                    // included: indices past the list are never dereferenced
-                    if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
-                }
-            }
-        }
+        const Hit h = find_hit(w, pos, o, d, alw, ncand_total);
         w.hit_idx[pos] = h.idx;
         w.hit_p[pos] = h.p.x; w.hit_p[n_slots + pos] = h.p.y; w.hit_p[2 * n_slots + pos] = h.p.z;
     }
@@ -902,12 +912,21 @@ __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
     if (lane == 0 && cn) atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
 }
 
-// one segment of add_to_path per queued ray; survivors are packed into the next queue
-__global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
+// one segment of add_to_path per queued ray; survivors are packed into the next queue.  FUSED: the narrow
+// phase runs here too (no hit records through memory, one launch less per round).
+template <bool FUSED>
+__global__ __launch_bounds__(256, SHADE_WAVES) void shade_kernel(const WfParams w) {
+    extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
+    if (count == 0) return;
+    if (FUSED) {
+        for (int i = threadIdx.x; i < w.kp.always_doubles; i += 256) alw[i] = w.kp.always[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int qi = w.iter & 1, qo = qi ^ 1;
     unsigned nrays = 0;
+    unsigned long long ncand_total = 0;
     const unsigned stride = gridDim.x * blockDim.x;
     const size_t n_slots = w.slots;
     // every lane of a wave runs the same number of trips so that the ballot below sees whole waves
@@ -921,9 +940,13 @@ __global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
             slot = w.queue[qi][pos];
             load_state(w, slot, s);
             Hit h;
-            h.len = 0.0;
-            h.idx = w.hit_idx[pos];
-            h.p = dmk(w.hit_p[pos], w.hit_p[n_slots + pos], w.hit_p[2 * n_slots + pos]);
+            if (FUSED) {
+                h = find_hit(w, pos, s.o, s.d, alw, ncand_total);
+            } else {
+                h.len = 0.0;
+                h.idx = w.hit_idx[pos];
+                h.p = dmk(w.hit_p[pos], w.hit_p[n_slots + pos], w.hit_p[2 * n_slots + pos]);
+            }
             nrays++;
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
@@ -939,9 +962,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const WfParams w) {
             if (alive) emit_ray(w, base + rank, slot, s, qo);
         }
     }
-    unsigned long long r = nrays;
-    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
-    if (lane == 0 && r) atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
+    unsigned long long r = nrays, cn = ncand_total;
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
+    if (lane == 0 && r) {
+        atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
+        if (cn) atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
+    }
 }
 
 // fn: 0 sin, 1 cos, 2 acos, 3 pow, 4 x/y, 5 sqrt(x), 6 next RNG state of (uint64)x bits
@@ -1025,6 +1051,7 @@ struct rt_context {
     // options
     int mode = RT_MODE_PIPELINE;
     int timing_detail = 0;
+    int fuse_narrow = 1;       // pipeline: narrow phase inside shade_kernel instead of a kernel of its own
     int block = 256;           // single-kernel renderer: workgroup size
     int broad_block = 512;     // broad_kernel workgroup size
     int grid_mult = 0;         // workgroups per CU, 0 = ask the occupancy API
@@ -1163,6 +1190,7 @@ int rt_create(rt_handle* out, int device) {
     hipEventCreate(&h->ev1);
     // tuning knobs for experiments; rt_set_option is the API for the same values
     if (const char* e = getenv("RT_MODE")) rt_set_option(h, RT_OPT_MODE, strcmp(e, "mega") == 0 ? RT_MODE_SINGLE_KERNEL : RT_MODE_PIPELINE);
+    if (const char* e = getenv("RT_FUSE")) rt_set_option(h, RT_OPT_FUSE_NARROW, atoi(e));
     if (const char* e = getenv("RT_BLOCK")) rt_set_option(h, RT_OPT_BLOCK, atoi(e));
     if (const char* e = getenv("RT_BROAD_BLOCK")) rt_set_option(h, RT_OPT_BROAD_BLOCK, atoi(e));
     if (const char* e = getenv("RT_WG_PER_CU")) rt_set_option(h, RT_OPT_WG_PER_CU, atoi(e));
@@ -1178,6 +1206,7 @@ int rt_set_option(rt_handle h, int key, int value) {
             if (value != RT_MODE_PIPELINE && value != RT_MODE_SINGLE_KERNEL) return fail(h, RT_ERR_ARG, "rt_set_option: bad mode");
             h->mode = value; return RT_OK;
         case RT_OPT_TIMING_DETAIL: h->timing_detail = value != 0; return RT_OK;
+        case RT_OPT_FUSE_NARROW: h->fuse_narrow = value != 0; return RT_OK;
         case RT_OPT_BLOCK:
             if (value != 256 && value != 512 && value != 1024) return fail(h, RT_ERR_ARG, "rt_set_option: block must be 256, 512 or 1024");
             h->block = value; return RT_OK;
@@ -1606,8 +1635,12 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
             else e = launch_broad<512>(h, w, bgrid, st);
             if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
             if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
-            hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
-            hipLaunchKernelGGL(shade_kernel, dim3(sgrid), dim3(256), 0, st, w);
+            if (h->fuse_narrow) {
+                hipLaunchKernelGGL(shade_kernel<true>, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
+            } else {
+                hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
+                hipLaunchKernelGGL(shade_kernel<false>, dim3(sgrid), dim3(256), 0, st, w);
+            }
         }
         e = hipGetLastError();
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("pipeline launch: ") + hipGetErrorString(e));
