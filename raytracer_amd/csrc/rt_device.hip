@@ -709,8 +709,8 @@ struct WfParams {
     unsigned slots;            // pixel slots of this batch
     unsigned item_base;        // first local pixel index of the batch
     int iter;                  // iteration number: queue iter&1 is read, (iter+1)&1 written
-    int* si;                   // [SI_COUNT][slots]
-    double* sd;                // [SD_COUNT][slots]
+    int* si[2];                // [SI_COUNT][slots] by queue position, one copy per queue: a surviving ray's state moves
+    double* sd[2];             // [SD_COUNT][slots]   with it to its place in the next queue, so both sides are coalesced
     double* acc;               // [3][slots] radiance sum of the slot's pixel (used when paths_per_pixel > 1)
     double* stack;             // [3*max_verts][slots]
     unsigned* queue[2];        // slot ids of the live rays
@@ -723,12 +723,13 @@ struct WfParams {
     int* hit_idx;              // [slots] by queue position: file index of the solid hit, -1 = none
 };
 
-DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
+DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, PathState& s) {
     const size_t n = w.slots;
-    s.rng = (unsigned)w.si[SI_RNG * n + slot];
-    s.sample = w.si[SI_SAMPLE * n + slot];
-    const int pk = w.si[SI_PACK * n + slot];
-    s.pv_mat = w.si[SI_PVMAT * n + slot];
+    const int* si = w.si[q] + pos;
+    s.rng = (unsigned)si[SI_RNG * n];
+    s.sample = si[SI_SAMPLE * n];
+    const int pk = si[SI_PACK * n];
+    s.pv_mat = si[SI_PVMAT * n];
     s.remaining = (int)(signed char)(pk & 0xff);
     s.nverts = (pk >> 8) & 0xff;
     s.flags = (pk >> 16) & 0xff;
@@ -737,22 +738,23 @@ DEV void load_state(const WfParams& w, unsigned slot, PathState& s) {
     s.n_cur = (s.flags & FL_INSIDE) ? w.kp.mats[s.pv_mat].rindex : 1.0;
     s.acc0 = s.acc1 = s.acc2 = 0.0;
     s.acc_mem = w.acc + slot; s.acc_stride = n;
-    const double* d = w.sd + slot;
+    const double* d = w.sd[q] + pos;
     s.o = dmk(d[(SD_O + 0) * n], d[(SD_O + 1) * n], d[(SD_O + 2) * n]);
     s.d = dmk(d[(SD_D + 0) * n], d[(SD_D + 1) * n], d[(SD_D + 2) * n]);
     s.pv_n = dmk(d[(SD_PVN + 0) * n], d[(SD_PVN + 1) * n], d[(SD_PVN + 2) * n]);
     s.pv_r = dmk(d[(SD_PVR + 0) * n], d[(SD_PVR + 1) * n], d[(SD_PVR + 2) * n]);
 }
 
-DEV void store_state(const WfParams& w, unsigned slot, const PathState& s) {
+DEV void store_state(const WfParams& w, int q, unsigned pos, const PathState& s) {
     const size_t n = w.slots;
-    w.si[SI_RNG * n + slot] = (int)s.rng;
-    w.si[SI_SAMPLE * n + slot] = s.sample;
+    int* si = w.si[q] + pos;
+    si[SI_RNG * n] = (int)s.rng;
+    si[SI_SAMPLE * n] = s.sample;
     // the refraction index is 1 unless the last bounce entered a solid, and then it is that solid's (= pv_mat's) index
     const int flags = (s.flags & (FL_FIRST_SEG | FL_PV_REFLECT)) | ((s.n_cur != 1.0) ? FL_INSIDE : 0);
-    w.si[SI_PACK * n + slot] = (s.remaining & 0xff) | ((s.nverts & 0xff) << 8) | (flags << 16);
-    w.si[SI_PVMAT * n + slot] = s.pv_mat;
-    double* d = w.sd + slot;
+    si[SI_PACK * n] = (s.remaining & 0xff) | ((s.nverts & 0xff) << 8) | (flags << 16);
+    si[SI_PVMAT * n] = s.pv_mat;
+    double* d = w.sd[q] + pos;
     d[(SD_O + 0) * n] = s.o.x; d[(SD_O + 1) * n] = s.o.y; d[(SD_O + 2) * n] = s.o.z;
     d[(SD_D + 0) * n] = s.d.x; d[(SD_D + 1) * n] = s.d.y; d[(SD_D + 2) * n] = s.d.z;
     d[(SD_PVN + 0) * n] = s.pv_n.x; d[(SD_PVN + 1) * n] = s.pv_n.y; d[(SD_PVN + 2) * n] = s.pv_n.z;
@@ -761,6 +763,7 @@ DEV void store_state(const WfParams& w, unsigned slot, const PathState& s) {
 
 DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathState& s, int q) {
     w.queue[q][pos] = slot;
+    store_state(w, q, pos, s);
     const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
     w.rec[0][pos] = r.a; w.rec[1][pos] = r.b;
 }
@@ -775,7 +778,6 @@ __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
         s.pv_mat = 0; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
         s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
         begin_pixel(s, item, w.kp);
-        store_state(w, slot, s);
         emit_ray(w, slot, slot, s, 0);
     }
 }
@@ -899,8 +901,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
     const unsigned stride = gridDim.x * blockDim.x;
     const size_t n_slots = w.slots;
     for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
-        const unsigned slot = w.queue[qi][pos];
-        const double* sd = w.sd + slot;
+        const double* sd = w.sd[qi] + pos;
         const d3 o = dmk(sd[(SD_O + 0) * n_slots], sd[(SD_O + 1) * n_slots], sd[(SD_O + 2) * n_slots]);
         const d3 d = dmk(sd[(SD_D + 0) * n_slots], sd[(SD_D + 1) * n_slots], sd[(SD_D + 2) * n_slots]);
         const Hit h = find_hit(w, pos, o, d, alw, ncand_total);
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void shade_kernel(const WfParams 
         unsigned slot = 0;
         if (pos < count) {
             slot = w.queue[qi][pos];
-            load_state(w, slot, s);
+            load_state(w, qi, pos, slot, s);
             Hit h;
             if (FUSED) {
                 h = find_hit(w, pos, s.o, s.d, alw, ncand_total);
@@ -950,7 +951,6 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void shade_kernel(const WfParams 
             nrays++;
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
-            if (alive) store_state(w, slot, s);
         }
         // pack the surviving rays into the next queue: rank within the wave's ballot, one atomic per wave
         const unsigned long long m = __ballot(alive);
@@ -1033,7 +1033,7 @@ struct rt_context {
     unsigned long long* d_stream_rays = nullptr; int stream_cap = 0;
     // pipeline state (per-pixel mode), sized for wf_slots pixel slots and wf_verts stack entries
     size_t wf_slots = 0; int wf_verts = 0; int wf_iters = 0;
-    int* wf_si = nullptr; double* wf_sd = nullptr; double* wf_stack = nullptr; double* wf_acc = nullptr;
+    int* wf_si[2] = {nullptr, nullptr}; double* wf_sd[2] = {nullptr, nullptr}; double* wf_stack = nullptr; double* wf_acc = nullptr;
     unsigned* wf_queue[2] = {nullptr, nullptr};
     unsigned* wf_counts = nullptr;
     float4* wf_rec[2] = {nullptr, nullptr};
@@ -1079,10 +1079,11 @@ void free_scene(rt_context* h) {
 }
 
 void free_pipeline(rt_context* h) {
-    hipFree(h->wf_si); hipFree(h->wf_sd); hipFree(h->wf_stack); hipFree(h->wf_queue[0]); hipFree(h->wf_queue[1]);
+    for (int q = 0; q < 2; q++) { hipFree(h->wf_si[q]); hipFree(h->wf_sd[q]); h->wf_si[q] = nullptr; h->wf_sd[q] = nullptr; }
+    hipFree(h->wf_stack); hipFree(h->wf_queue[0]); hipFree(h->wf_queue[1]);
     hipFree(h->wf_counts); hipFree(h->wf_rec[0]); hipFree(h->wf_rec[1]); hipFree(h->wf_acc);
     hipFree(h->wf_cand); hipFree(h->wf_cand_cnt); hipFree(h->wf_hit_p); hipFree(h->wf_hit_idx);
-    h->wf_si = nullptr; h->wf_sd = nullptr; h->wf_stack = nullptr; h->wf_queue[0] = h->wf_queue[1] = nullptr;
+    h->wf_stack = nullptr; h->wf_queue[0] = h->wf_queue[1] = nullptr;
     h->wf_counts = nullptr; h->wf_rec[0] = h->wf_rec[1] = nullptr; h->wf_acc = nullptr; h->wf_cand = nullptr; h->wf_cand_cnt = nullptr; h->wf_hit_p = nullptr; h->wf_hit_idx = nullptr;
     h->wf_slots = 0; h->wf_verts = 0; h->wf_iters = 0;
 }
@@ -1562,8 +1563,8 @@ static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int
 static int ensure_pipeline(rt_handle h, size_t slots, int verts, int iters) {
     if (h->wf_slots >= slots && h->wf_verts >= verts && h->wf_iters >= iters) return RT_OK;
     free_pipeline(h);
-    HIP_TRY(h, hipMalloc((void**)&h->wf_si, slots * SI_COUNT * sizeof(int)));
-    HIP_TRY(h, hipMalloc((void**)&h->wf_sd, slots * SD_COUNT * sizeof(double)));
+    for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_si[q], slots * SI_COUNT * sizeof(int)));
+    for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_sd[q], slots * SD_COUNT * sizeof(double)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_stack, slots * (size_t)verts * 3 * sizeof(double)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->wf_queue[q], slots * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc((void**)&h->wf_counts, ((size_t)iters + 2) * sizeof(unsigned)));
@@ -1596,7 +1597,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     w.kp.max_verts = verts;
     w.kp.total_items = (unsigned)total;
     w.kp.rgb = d_rgb; w.kp.hit_ids = d_hit_ids;
-    w.si = h->wf_si; w.sd = h->wf_sd; w.stack = h->wf_stack;
+    for (int q = 0; q < 2; q++) { w.si[q] = h->wf_si[q]; w.sd[q] = h->wf_sd[q]; }
+    w.stack = h->wf_stack;
     w.queue[0] = h->wf_queue[0]; w.queue[1] = h->wf_queue[1];
     w.counts = h->wf_counts;
     for (int q = 0; q < 2; q++) w.rec[q] = h->wf_rec[q];
@@ -1609,7 +1611,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     else if (h->broad_block == 256) e = broad_grid<256>(h, &bgrid);
     else e = broad_grid<512>(h, &bgrid);
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
-    const unsigned sgrid = (unsigned)h->cu_count * 8u;
+    unsigned sgrid = (unsigned)h->cu_count * 16u;
+    if (const char* e = getenv("RT_SHADE_GRID")) sgrid = (unsigned)h->cu_count * (unsigned)atoi(e);
     h->last_streams = 0;
     h->broad_ev_used = 0;
     if (h->timing_detail) {
