@@ -150,7 +150,8 @@ def main():
                          "kernel": "broad_kernel (all launches of one frame)", "kernel_ms": broad_ms,
                          "frame_kernels_ms": frame_kernels_ms,
                          "frac_whole_frame": flops_local / (frame_kernels_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                         "rays_this_gpu": rays_local, "candidates_per_ray": tm["candidates"] / max(1, tm["rays"])},
+                         "rays_this_gpu": rays_local, "candidates_per_ray": tm["candidates"] / max(1, tm["rays"]),
+                         "overflow_rays": tm.get("overflow_rays", 0)},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)

@@ -98,6 +98,7 @@ typedef struct {
     uint64_t plane_tests;
     uint64_t face_tests;
     uint64_t face_vert_tests;
+    uint64_t overflow_rays; /* pipeline: rays whose candidate list overflowed and were tested against every solid */
 } rt_timing;
 
 /* options for rt_set_option */

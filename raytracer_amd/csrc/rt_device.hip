@@ -109,7 +109,7 @@ struct KParams {
     double* rgb;
     int* hit_ids;
     unsigned long long* stream_rays;
-    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64)
+    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64), [6] rays whose candidate list overflowed
 };
 
 struct d3 { double x, y, z; };
@@ -690,12 +690,18 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 //                                   next queue by ballot rank (one atomic per wave)
 // until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
 // small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
+#ifndef SHADE_BLOCK
+#define SHADE_BLOCK 512
+#endif
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
 constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS windows are multiples of it
 constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
-constexpr int WF_CAND_CAP = 16;        // non-zero mask words kept per ray; beyond that the ray gets a full exact scan
+#ifndef WF_CAND_CAP_N
+#define WF_CAND_CAP_N 16
+#endif
+constexpr int WF_CAND_CAP = WF_CAND_CAP_N;        // non-zero mask words kept per ray; beyond that the ray gets a full exact scan
 constexpr unsigned WF_OVERFLOW = 0xffffffffu;
 // per-slot state kept between rounds: 4 ints + 12 doubles (+ 3 doubles of radiance sum, touched at path ends only).
 // Not stored: pixel coordinates (a function of the slot), the current refraction index (1, or the index of the
@@ -867,6 +873,7 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, d3 o, d3 d, const double* alw,
         // more non-zero words than list entries: exact test against the whole list
         for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
         ncand_total += (unsigned)w.kp.n_prims;
+        atomicAdd(&w.kp.ctrl[6], 1u);
         return h;
     }
     narrow_always(alw, w.kp.n_always, o, d, h);
@@ -916,21 +923,22 @@ __global__ __launch_bounds__(256) void narrow_kernel(const WfParams w) {
 // one segment of add_to_path per queued ray; survivors are packed into the next queue.  FUSED: the narrow
 // phase runs here too (no hit records through memory, one launch less per round).
 template <bool FUSED>
-__global__ __launch_bounds__(256, SHADE_WAVES) void shade_kernel(const WfParams w) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w) {
     extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     if (FUSED) {
-        for (int i = threadIdx.x; i < w.kp.always_doubles; i += 256) alw[i] = w.kp.always[i];
+        for (int i = threadIdx.x; i < w.kp.always_doubles; i += SHADE_BLOCK) alw[i] = w.kp.always[i];
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned wg_cnt[2][SHADE_BLOCK / 64], wg_base[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int qi = w.iter & 1, qo = qi ^ 1;
     unsigned nrays = 0;
     unsigned long long ncand_total = 0;
     const unsigned stride = gridDim.x * blockDim.x;
     const size_t n_slots = w.slots;
-    // every lane of a wave runs the same number of trips so that the ballot below sees whole waves
+    // every lane of a workgroup runs the same number of trips so that the ballot below sees whole waves
     const unsigned trips = (count + stride - 1) / stride;
     for (unsigned t = 0; t < trips; t++) {
         const unsigned pos = t * stride + blockIdx.x * blockDim.x + threadIdx.x;
@@ -952,20 +960,34 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void shade_kernel(const WfParams 
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
         }
-        // pack the surviving rays into the next queue: rank within the wave's ballot, one atomic per wave
+        // pack the surviving rays into the next queue: rank within the wave's ballot, the waves' survivor counts
+        // meet in LDS (double-buffered by trip parity) and the workgroup takes its range with ONE atomic --
+        // an atomic per wave on the one counter costs more than a millisecond per frame
         const unsigned long long m = __ballot(alive);
-        if (m != 0ull) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&w.counts[w.iter + 1], (unsigned)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (alive) emit_ray(w, base + rank, slot, s, qo);
+        unsigned* cnt = wg_cnt[t & 1];
+        if (lane == 0) cnt[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += cnt[k];
+            wg_base[t & 1] = tot ? atomicAdd(&w.counts[w.iter + 1], tot) : 0u;
         }
+        __syncthreads();
+        unsigned base = wg_base[t & 1];
+        for (int k = 0; k < wv; k++) base += cnt[k];
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (alive) emit_ray(w, base + rank, slot, s, qo);
     }
+    // ray and candidate totals: wave sums through LDS, one atomic pair per workgroup
     unsigned long long r = nrays, cn = ncand_total;
     for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
-    if (lane == 0 && r) {
-        atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
+    __shared__ unsigned long long wg_tot[2][SHADE_BLOCK / 64];
+    if (lane == 0) { wg_tot[0][wv] = r; wg_tot[1][wv] = cn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r = 0; cn = 0;
+        for (int k = 0; k < SHADE_BLOCK / 64; k++) { r += wg_tot[0][k]; cn += wg_tot[1][k]; }
+        if (r) atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
         if (cn) atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
     }
 }
@@ -1639,10 +1661,10 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
             if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
             if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], st));
             if (h->fuse_narrow) {
-                hipLaunchKernelGGL(shade_kernel<true>, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
+                hipLaunchKernelGGL(shade_kernel<true>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), (size_t)h->always_doubles * sizeof(double), st, w);
             } else {
                 hipLaunchKernelGGL(narrow_kernel, dim3(sgrid), dim3(256), (size_t)h->always_doubles * sizeof(double), st, w);
-                hipLaunchKernelGGL(shade_kernel<false>, dim3(sgrid), dim3(256), 0, st, w);
+                hipLaunchKernelGGL(shade_kernel<false>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, w);
             }
         }
         e = hipGetLastError();
@@ -1684,7 +1706,7 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->events_pending = false;
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    unsigned ctrl[6];
+    unsigned ctrl[8];
     HIP_TRY(h, hipMemcpy(ctrl, h->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     uint64_t r = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
     h->timing.kernel_ms = ms;
@@ -1695,6 +1717,7 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     }
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
+    h->timing.overflow_rays = ctrl[6];
     h->timing.sphere_tests = r * h->n_spheres;
     h->timing.plane_tests = r * h->n_planes;
     h->timing.face_tests = r * h->n_faces;
