@@ -22,6 +22,22 @@ int oracle_render(const double* params, int n_prims, const double* prims, int n_
     return -2;
 }
 
+// Debugging aid: one pixel in per-pixel RNG order (device policy), every segment printed to stderr.
+int oracle_trace_pixel(const double* params, int n_prims, const double* prims, int n_mats, const double* mats,
+                       int n_verts, const double* verts, int x, int y, double* rgb) {
+    SceneD sc;
+    sc.n_prims = n_prims; sc.prims = prims; sc.n_mats = n_mats; sc.mats = mats; sc.n_verts = n_verts; sc.verts = verts;
+    Tracer<DevPolicy> tr;
+    tr.load(sc, params);
+    tr.log = stderr;
+    Rng g; g.s = pixel_seed((uint32_t)(y * tr.width + x), tr.frame_seed);
+    long rays = 0;
+    double out[3];
+    tr.pixel(x, y, g, &rays, out, nullptr);
+    for (int k = 0; k < 3; k++) rgb[k] = out[k];
+    return tr.guard_tripped ? -1 : 0;
+}
+
 void oracle_expose(int width, int height, double exposure, int num_blurs, int n_workers, double* rgb, int32_t* img) {
     expose(width, height, exposure, num_blurs, n_workers, rgb, img);
 }

@@ -84,6 +84,22 @@ def render(scene, policy=POLICY_DEV, rng_mode=RNG_PIXEL, workers=None, rows=None
     return dict(rgb=rgb, rays=rays, hits=hits, pix_rays=pix)
 
 
+def trace_pixel(scene, x, y):
+    """Debugging aid: renders one pixel (device policy, per-pixel seed) and prints every segment to stderr."""
+    l = lib()
+    params = scene.params()
+    prims = np.ascontiguousarray(scene.prims, dtype=np.float64)
+    mats = np.ascontiguousarray(scene.mats, dtype=np.float64)
+    verts = np.ascontiguousarray(scene.verts, dtype=np.float64)
+    if verts.size == 0:
+        verts = np.zeros((1, 3))
+    rgb = np.zeros(3)
+    l.oracle_trace_pixel.restype = C.c_int
+    rc = l.oracle_trace_pixel(_dp(params), len(prims), _dp(prims), len(mats), _dp(mats), len(scene.verts), _dp(verts),
+                              C.c_int(x), C.c_int(y), _dp(rgb))
+    return rc, rgb
+
+
 def expose(rgb, exposure, num_blurs, workers=None):
     """Bloom + 8-bit pack; returns (int32[H,W] packed 0xRRGGBB, float64 rgb with bloom added)."""
     l = lib()

@@ -31,6 +31,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <cstdio>
 #include <vector>
 
 #include "rt_oracle_math.hpp"
@@ -127,6 +128,7 @@ struct Tracer {
     R scale = 0, lens = 0, focal = 0;
     uint32_t frame_seed = 0;
     bool guard_tripped = false;
+    FILE* log = nullptr;          // when set, trace() prints one line per segment (debugging aid)
 
     static R INF() { return std::numeric_limits<R>::infinity(); }
     static R NaN() { return std::numeric_limits<R>::quiet_NaN(); }
@@ -351,6 +353,10 @@ struct Tracer {
             int mi = -1;
             int hit = closest(o, d, &p, &normal, &mi);
             if (seg == 0 && first_hit) *first_hit = hit;
+            if (log) std::fprintf(log, "  seg %ld o (%.17g %.17g %.17g) d (%.17g %.17g %.17g) hit %d p (%.17g %.17g %.17g) n.d %.6g mat %d rindex %g n_cur %g remaining %d\n",
+                                  seg, (double)o.v[0], (double)o.v[1], (double)o.v[2], (double)d.v[0], (double)d.v[1], (double)d.v[2], hit,
+                                  (double)p.v[0], (double)p.v[1], (double)p.v[2], (double)dot(normal, d), mi, mi >= 0 ? (double)mats[mi].rindex : -1.0,
+                                  (double)n_cur, remaining);
             if (mi >= 0 && mats[mi].is_light) { term = p; term_mat = mi; lit = true; break; }   // main.cpp:132-135
             if (!valid(p)) break;                                                                // main.cpp:179-182
             if (remaining == 0 && first_light >= 0) { light_draws(g); break; }                   // main.cpp:137-153 (always black)

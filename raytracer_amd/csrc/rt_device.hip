@@ -161,7 +161,7 @@ __host__ __device__ inline unsigned pixel_seed(unsigned pixel_index, unsigned fr
 }
 
 struct Hit {
-    double len;     // |p - o| of the closest accepted hit so far (get_intersection's criterion)
+    double q;       // |p - o|^2 (as the reference rounds it, before its square root) of the closest accepted hit so far
     int idx;        // file index of its solid, -1 = none
     d3 p;
 };
@@ -169,10 +169,23 @@ struct Hit {
 // get_intersection's acceptance, main.cpp:37: scanning in file order and taking a candidate iff its point is
 // valid and strictly nearer selects the smallest (distance, file index) pair.  Written as that pair
 // comparison, the selection no longer depends on the order in which candidates are examined.
+// The reference compares len = sqrt(q).  The correctly rounded square root is monotonic, and two arguments
+// that differ by more than 2^-50 relative have roots that differ by more than 2^-51 relative -- more than
+// the two roundings (2^-53 each) can close -- so outside that band the squared lengths decide and the square
+// roots (the most expensive instructions of the test) are only taken inside it.
 DEV void consider(d3 p, int idx, d3 o, Hit& h) {
     if (!dvalid(p)) return;
-    double len = dlen(dsub(p, o));
-    if (h.len > len || (h.len == len && idx < h.idx)) { h.len = len; h.idx = idx; h.p = p; }
+    const d3 v = dsub(p, o);
+    const double q = ddot(v, v);
+    const double band = 8.8817841970012523e-16;      // 2^-50
+    bool take;
+    if (q < h.q * (1.0 - band)) take = true;
+    else if (q > h.q * (1.0 + band)) take = false;
+    else {
+        const double len = __builtin_sqrt(q), hl = __builtin_sqrt(h.q);
+        take = hl > len || (hl == len && idx < h.idx);
+    }
+    if (take) { h.q = q; h.idx = idx; h.p = p; }
 }
 
 // Sphere::intersect, geometry.cpp:129-138
@@ -235,7 +248,7 @@ DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
 // branch (:48-77, power-cosine lobe about the mirror direction, rejection loop) and the diffuse branch
 // (:78-103, uniform hemisphere about the normal) build their sample the same way about different axes;
 // they share one instruction stream here, each lane keeping its own branch's operation sequence.
-DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* err) {
+DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* err, unsigned item) {
     const double PI = 3.14159265358979323846;
     const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
     const bool glossy = rng_next(rng) < m.gloss_thr;
@@ -256,7 +269,7 @@ DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* e
         const d3 v = dmk(sr * cp, sr * sp, u);
         nd = flat ? v : rotate3(v, n, cost, sint);
         if (!glossy || ddot(nd, normal) >= 0.0) break;
-        if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); break; }
+        if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); atomicMax(err + 6, item + 1u); break; }
     }
     return nd;
 }
@@ -480,7 +493,7 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
             change = 0;
         } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                   // main.cpp:164-167
-            fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1]);
+            fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1], item);
             reflect = true;
         } else {                                                                       // main.cpp:168-171
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 
         // ---- closest hit (get_intersection, main.cpp:34-43)
         Hit h;
-        h.len = __builtin_inf(); h.idx = -1;
+        h.q = __builtin_inf(); h.idx = -1;
         h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
         int ncand = 0;
         auto narrow = [&]() {
@@ -690,6 +703,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 //                                   next queue by ballot rank (one atomic per wave)
 // until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
 // small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
+#ifndef SHADE_PROFILE
+#define SHADE_PROFILE 0
+#endif
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
@@ -866,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
 // through the reference's exact test
 DEV Hit find_hit(const WfParams& w, unsigned pos, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
     Hit h;
-    h.len = __builtin_inf(); h.idx = -1;
+    h.q = __builtin_inf(); h.idx = -1;
     h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
     const unsigned n = w.cand_cnt[pos];
     if (n == WF_OVERFLOW) {
@@ -931,6 +947,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         for (int i = threadIdx.x; i < w.kp.always_doubles; i += SHADE_BLOCK) alw[i] = w.kp.always[i];
         __syncthreads();
     }
+#if SHADE_PROFILE
+    // wave-cycles per section (find_hit | segment | barriers | emit), summed over waves into ctrl[16..]
+    unsigned long long prof[5] = {0, 0, 0, 0, 0};
+    unsigned long long tick = __builtin_amdgcn_s_memtime();
+#define SHADE_TICK(k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); prof[k] += now - tick; tick = now; }
+#else
+#define SHADE_TICK(k)
+#endif
     __shared__ unsigned wg_cnt[2][SHADE_BLOCK / 64], wg_base[2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int qi = w.iter & 1, qo = qi ^ 1;
@@ -945,14 +969,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         bool alive = false;
         PathState s;
         unsigned slot = 0;
+        SHADE_TICK(0);
         if (pos < count) {
             slot = w.queue[qi][pos];
             load_state(w, qi, pos, slot, s);
             Hit h;
             if (FUSED) {
                 h = find_hit(w, pos, s.o, s.d, alw, ncand_total);
+                SHADE_TICK(1);
             } else {
-                h.len = 0.0;
+                h.q = 0.0;
                 h.idx = w.hit_idx[pos];
                 h.p = dmk(w.hit_p[pos], w.hit_p[n_slots + pos], w.hit_p[2 * n_slots + pos]);
             }
@@ -960,6 +986,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
         }
+        SHADE_TICK(2);
         // pack the surviving rays into the next queue: rank within the wave's ballot, the waves' survivor counts
         // meet in LDS (double-buffered by trip parity) and the workgroup takes its range with ONE atomic --
         // an atomic per wave on the one counter costs more than a millisecond per frame
@@ -973,11 +1000,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             wg_base[t & 1] = tot ? atomicAdd(&w.counts[w.iter + 1], tot) : 0u;
         }
         __syncthreads();
+        SHADE_TICK(3);
         unsigned base = wg_base[t & 1];
         for (int k = 0; k < wv; k++) base += cnt[k];
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (alive) emit_ray(w, base + rank, slot, s, qo);
+        SHADE_TICK(4);
     }
+#if SHADE_PROFILE
+    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)(w.kp.ctrl + 16 + 2 * k), prof[k]);
+#endif
     // ray and candidate totals: wave sums through LDS, one atomic pair per workgroup
     unsigned long long r = nrays, cn = ncand_total;
     for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
@@ -1208,7 +1240,7 @@ int rt_create(rt_handle* out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
     h->cu_count = prop.multiProcessorCount;
-    if (hipMalloc((void**)&h->d_ctrl, 64) != hipSuccess) { delete h; return RT_ERR_HIP; }
+    if (hipMalloc((void**)&h->d_ctrl, 256) != hipSuccess) { delete h; return RT_ERR_HIP; }
     hipEventCreate(&h->ev0);
     hipEventCreate(&h->ev1);
     // tuning knobs for experiments; rt_set_option is the API for the same values
@@ -1566,7 +1598,7 @@ static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int
     }
     h->last_streams = stream_mode ? h->num_threads : 0;
     kp.rgb = d_rgb; kp.hit_ids = d_hit_ids;
-    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 64, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (kp.total_items > 0) {
         hipError_t e;
@@ -1641,7 +1673,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         const size_t need = (size_t)2 * iters * ((total + slots_cap - 1) / slots_cap ? (total + slots_cap - 1) / slots_cap : 1);
         while (h->broad_ev.size() < need) { hipEvent_t ev; HIP_TRY(h, hipEventCreate(&ev)); h->broad_ev.push_back(ev); }
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 64, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     for (uint64_t base = 0; base < total; base += slots_cap) {
         const uint64_t n = total - base < slots_cap ? total - base : slots_cap;
@@ -1718,12 +1750,22 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
     h->timing.overflow_rays = ctrl[6];
+#if SHADE_PROFILE
+    {
+        unsigned long long prof[5];
+        hipMemcpy(prof, h->d_ctrl + 16, sizeof(prof), hipMemcpyDeviceToHost);
+        fprintf(stderr, "shade wave-cycles: loop-top %llu  load+find_hit %llu  segment %llu  barriers %llu  emit %llu\n",
+                prof[0], prof[1], prof[2], prof[3], prof[4]);
+    }
+#endif
     h->timing.sphere_tests = r * h->n_spheres;
     h->timing.plane_tests = r * h->n_planes;
     h->timing.face_tests = r * h->n_faces;
     h->timing.face_vert_tests = r * h->n_face_verts;
     if (rays) *rays = r;
-    if (ctrl[1] & ERR_REJECT_GUARD) return fail(h, RT_ERR_GUARD, "render: the glossy rejection loop did not accept within its guard (a glossy surface hit from behind: the reference never terminates on this scene)");
+    if (ctrl[1] & ERR_REJECT_GUARD)
+        return fail(h, RT_ERR_GUARD, "render: the glossy rejection loop did not accept within its guard at local pixel " + std::to_string(ctrl[7] - 1u) +
+                                     " (a glossy surface hit from behind: the reference never terminates on this scene)");
     if (ctrl[1] & ERR_STACK) return fail(h, RT_ERR_GUARD, "render: bounce stack overflow (path longer than 2*max_ray_depth+2 vertices: no emitter in the scene?)");
     return RT_OK;
 }

@@ -88,10 +88,14 @@ RTM_FN double asin_poly(double x) {  // |x| <= 0.5: x + x^3 * (30-term Taylor ta
 // acos: pi/2 - asin(x) for |x| <= 1/2, else 2 asin(sqrt((1-|x|)/2)) reflected for x < 0.
 // |x| > 1 makes the sqrt argument negative, hence NaN.
 RTM_BIG double acosd(double x) {
-    double ax = absd(x);
-    if (ax <= 0.5) return (RTM_PIO2 - asin_poly(x)) + RTM_PIO2_LOW;
-    double z = (1.0 - ax) * 0.5;
-    double a = 2.0 * asin_poly(__builtin_sqrt(z));
+    // one polynomial evaluation serves both ranges (the lanes of a wave usually hold both)
+    const double ax = absd(x);
+    const bool small = ax <= 0.5;
+    const double z = (1.0 - ax) * 0.5;
+    const double t = small ? x : __builtin_sqrt(z);
+    const double as = asin_poly(t);
+    if (small) return (RTM_PIO2 - as) + RTM_PIO2_LOW;
+    const double a = 2.0 * as;
     return (x > 0.0) ? a : ((RTM_PI - a) + RTM_PI_LOW);
 }
 

@@ -31,10 +31,15 @@ BOX_HI = (19.0, 18.0, -1.0)
 
 def _room(n_emitters: int, extra_planes: int = 0):
     objs = []
+    # With planes behind the walls a ray that slips through a corner of the room (a hit nearer than the 0.001
+    # threshold is ignored, geometry.cpp:102) bounces around outside and can meet the floor from below: the floor
+    # must then not be glossy, or the reference's rejection loop never accepts.  Without those planes such a ray
+    # never comes back and the floor keeps the mirror-like finish of scene.json.
+    floor_spec = ([0, 0, 0], [0, 0, 0], 1) if extra_planes else ([0.3, 0.3, 0.3], [0.1, 0.1, 0.1], 1000)
     objs.append({"shape": "plane", "is_light": False, "point": [0, -20, 0], "normal": [0, 1, 0],
-                 "diffuse1": [0.7, 0.7, 0.7], "diffuse2": [0.1, 0.1, 0.1], "specular1": [0.3, 0.3, 0.3],
-                 "specular2": [0.1, 0.1, 0.1], "specular_exp": 1000, "refraction_index": 0})
-    # planes behind the walls: tested by every ray, never the closest hit
+                 "diffuse1": [0.7, 0.7, 0.7], "diffuse2": [0.1, 0.1, 0.1], "specular1": floor_spec[0],
+                 "specular2": floor_spec[1], "specular_exp": floor_spec[2], "refraction_index": 0})
+    # planes behind the walls: tested by every ray, the closest hit only for the rare ray that left the room
     behind = [([0, 0, -60], [0, 0, 1]), ([40, 0, 0], [-1, 0, 0]), ([-40, 0, 0], [1, 0, 0]), ([0, 40, 0], [0, -1, 0]),
               ([0, 0, -80], [0, 0, 1]), ([60, 0, 0], [-1, 0, 0]), ([-60, 0, 0], [1, 0, 0])]
     for pt, n in behind[:extra_planes]:
@@ -99,7 +104,10 @@ def _lattice_objects(rng, nx, ny, nz, count, glass_frac, quad_frac):
             glass = rng.random() < glass_frac
             o = {"shape": "sphere", "is_light": False, "center": c, "radius": r}
             if glass:
-                o.update({"diffuse": [0, 0, 0], "specular": [0.5, 0.5, 0.5], "specular_exp": 1000, "refraction_index": 1.5,
+                # a transparent solid can be met from inside with the path believing it is outside (an entry whose
+                # chord is shorter than the 0.001 hit threshold is never left): like every surface that can be hit
+                # from behind it must not be glossy, or the reference's rejection loop (main.cpp:61-76) never ends
+                o.update({"diffuse": [0.4, 0.4, 0.4], "specular": [0, 0, 0], "specular_exp": 1, "refraction_index": 1.5,
                           "refraction_diffuse": [0, 0, 0], "refraction_specular": [1.5, 1.5, 1.5], "refraction_specular_exp": 100})
             else:
                 o.update({"diffuse": [rng.uniform(0, 0.8) for _ in range(3)], "specular": [0.3, 0.3, 0.3], "specular_exp": 50,
