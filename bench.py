@@ -41,14 +41,14 @@ def algorithmic_flops(t, sc):
 
 
 def cpu_baseline(workload, cores):
-    """Time the CPU path on a bounded sample: the same scene at 1/4 linear resolution (identical
-    framing: scale = width/40).  Prefers the compiled reference binary; falls back to the oracle port."""
+    """Time the CPU path on a bounded sample (10-30 s of CPU work): the same scene at 1/2 linear resolution
+    (identical framing: scale = width/40).  Prefers the compiled reference binary; falls back to the oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     cfg = synth.CONFIGS[workload]
-    w = max(64, cfg["width"] // 4)
+    w = max(64, cfg["width"] // 2)
     text, sc = synth.make(workload, width=w, num_threads=cores)
-    sample = f"{workload} at {sc.width}x{sc.height} (1/4 linear resolution, same framing), {cores} threads, render+expose as main.cpp:305-315 times it"
+    sample = f"{workload} at {sc.width}x{sc.height} (1/2 linear resolution, same framing), {cores} threads, render+expose as main.cpp:305-315 times it"
     try:
         if po.have_reference():
             r = po.run_reference(text, num_threads=cores, num_blurs=0, timeout=900)
@@ -64,6 +64,19 @@ def cpu_baseline(workload, cores):
     rays = int(o["rays"].sum())
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
             "seconds": secs, "rays": rays}
+
+
+def measured_traffic(kernel_prefix):
+    """HBM bytes per frame of the kernel's launches, from the committed rocprofv3 --pmc passes of this workload
+    (profiles/r1/traffic.json, written by tools/summarize_profile.py); None when no such profile is present."""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))["kernels"]
+        for name, v in k.items():
+            if name.startswith(kernel_prefix):
+                return v["bytes_per_frame"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -146,7 +159,9 @@ def main():
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
                        "partition": f"cyclic row tiles over {world} GPU(s), gather to rank 0"},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                         "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,
+                         "traffic_unit": "HBM bytes per frame (all broad_kernel launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE",
                          "kernel": "broad_kernel (all launches of one frame)", "kernel_ms": broad_ms,
                          "frame_kernels_ms": frame_kernels_ms,
                          "frac_whole_frame": flops_local / (frame_kernels_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
