@@ -170,6 +170,18 @@ int rt_stream_rays(rt_handle h, uint64_t* out, int n);
 int rt_render(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids);
 int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids);
 
+/* expose() on the device: bloom of the over-exposed pixels (num_blurs passes of the 41x41 Gaussian, radius 20,
+ * sigma 3, taps outside the frame skipped) added to the radiance, then Color::to_int: int(255*c/(1/exposure))
+ * truncated, clamped to 255 from above only, packed r<<16 + g<<8 + b.  Double arithmetic in the reference's
+ * operation order: the packed frame equals the reference's bit for bit.  Asynchronous on `stream`.
+ *   d_rgb : double[height*width*3] un-exposed radiance (not modified; the reference adds the bloom in place)
+ *   d_img : int32[height*width] packed pixels, what writeImage takes (pngUtil.c:4)
+ * With num_blurs == 0 the rows are independent, so a rank may expose just the rows it rendered before the
+ * gather (height = its row count).  Replaces expose() + blur(), main.cpp:186-242, and Color::to_int,
+ * geometry.cpp:15-23. */
+int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
+                     int32_t* d_img, void* stream);
+
 /* Timing and work counters of the last upload/render (HIP-event device time). */
 int rt_last_timing(rt_handle h, rt_timing* out);
 

@@ -26,7 +26,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
           -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
-           "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams",
+           "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
 
 
@@ -76,6 +76,8 @@ def load_library(path: str = LIB_PATH):
     for f in (l.rt_render, l.rt_render_streams):
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    l.rt_expose_device.restype = C.c_int
+    l.rt_expose_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     l.rt_last_timing.restype = C.c_int
     l.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(RtTiming)]
     l.rt_last_error.restype = C.c_char_p
@@ -160,6 +162,11 @@ class Renderer:
         self._check(self.lib.rt_render_rows_device(self.h, int(tile_rows), int(rank), int(world), C.c_void_p(d_rgb_ptr),
                                                    C.c_void_p(d_hits_ptr) if d_hits_ptr else None,
                                                    C.c_void_p(stream) if stream else None))
+
+    def expose_device(self, d_rgb_ptr, width, height, exposure, num_blurs, d_img_ptr, stream=None):
+        """expose() on the device (bloom + 8-bit pack): double[height*width*3] -> int32[height*width], asynchronous."""
+        self._check(self.lib.rt_expose_device(self.h, C.c_void_p(d_rgb_ptr), int(width), int(height), float(exposure),
+                                              int(num_blurs), C.c_void_p(d_img_ptr), C.c_void_p(stream) if stream else None))
 
     def finish(self):
         rays = C.c_uint64(0)

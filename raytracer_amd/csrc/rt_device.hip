@@ -1024,6 +1024,66 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     }
 }
 
+// ---- expose(): bloom + 8-bit pack (main.cpp:186-242, geometry.cpp:15-23) -------------------------
+// Everything in double, every product and sum rounded on its own, taps in the reference's order (ky outer, kx
+// inner), so the packed frame is the reference's bit for bit.  A tap outside the frame is skipped by the
+// reference; here it reads +0.0 from the zero-filled border of the tile, and acc + (+0.0 * k) == acc because
+// acc never is -0.0 (it starts at +0.0 and a sum of doubles is -0.0 only when both terms are).
+constexpr int BLOOM_R = 20, BLOOM_K = 2 * BLOOM_R + 1, BLOOM_T = 16, BLOOM_TILE = BLOOM_T + 2 * BLOOM_R;
+
+// B0 of main.cpp:198-205: exposure where the channel is over-exposed, else 0
+__global__ void expose_mask_kernel(const double* rgb, double* cur, size_t n3, double exposure) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (size_t)gridDim.x * blockDim.x)
+        cur[i] = (rgb[i] * exposure > 1.0) ? exposure : 0.0;
+}
+
+// one pass of main.cpp:207-223 for one channel (blockIdx.z) of a 16x16 tile of pixels
+__global__ __launch_bounds__(BLOOM_T * BLOOM_T) void bloom_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                                  int W, int H, const double* __restrict__ kern) {
+    __shared__ double tile[BLOOM_TILE][BLOOM_TILE + 1];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * BLOOM_T - BLOOM_R, y0 = blockIdx.y * BLOOM_T - BLOOM_R;
+    for (int i = threadIdx.x; i < BLOOM_TILE * BLOOM_TILE; i += BLOOM_T * BLOOM_T) {
+        const int ty = i / BLOOM_TILE, tx = i - ty * BLOOM_TILE;
+        const int x = x0 + tx, y = y0 + ty;
+        tile[ty][tx] = (x >= 0 && x < W && y >= 0 && y < H) ? src[((size_t)y * W + x) * 3 + ch] : 0.0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % BLOOM_T, ly = threadIdx.x / BLOOM_T;
+    double c = 0.0;
+    for (int ky = 0; ky < BLOOM_K; ky++) {
+        const double* krow = kern + ky * BLOOM_K;
+#pragma unroll 1
+        for (int kx = 0; kx < BLOOM_K; kx++) c = c + tile[ly + ky][lx + kx] * krow[kx];
+    }
+    const int x = blockIdx.x * BLOOM_T + lx, y = blockIdx.y * BLOOM_T + ly;
+    if (x < W && y < H) dst[((size_t)y * W + x) * 3 + ch] = c;
+}
+
+// (int)x as the reference's compiler converts it (cvttsd2si): truncation, 0x80000000 when out of range or NaN
+DEV int to_int_x86(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000u;
+    return (int)v;
+}
+
+// main.cpp:225-227 + 237-241 with Color::to_int (geometry.cpp:15-23).  bloom == nullptr: no blur pass was
+// asked for and the reference adds B0 itself.
+__global__ void expose_pack_kernel(const double* rgb, const double* bloom, int* img, size_t n, double exposure) {
+    const double mx = 1.0 / exposure;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int v[3];
+        for (int k = 0; k < 3; k++) {
+            const double c = rgb[3 * i + k];
+            const double b = bloom ? bloom[3 * i + k] : ((c * exposure > 1.0) ? exposure : 0.0);
+            const double col = c + b;
+            int q = to_int_x86(255.0 * col / mx);
+            if (q > 255) q = 255;
+            v[k] = q;
+        }
+        img[i] = (int)(((unsigned)v[0] << 16) + ((unsigned)v[1] << 8) + (unsigned)v[2]);
+    }
+}
+
 // fn: 0 sin, 1 cos, 2 acos, 3 pow, 4 x/y, 5 sqrt(x), 6 next RNG state of (uint64)x bits
 __global__ void selftest_math_kernel(int fn, int n, const double* x, const double* y, double* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,6 +1159,8 @@ struct rt_context {
     double* d_rgb = nullptr; size_t d_rgb_bytes = 0;
     int32_t* d_hits = nullptr; size_t d_hits_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_bloom[2] = {nullptr, nullptr}; size_t bloom_doubles = 0;   // rt_expose_device scratch
+    double* d_bloom_kern = nullptr;
     bool events_pending = false;
     int last_streams = 0;
     rt_timing timing{};
@@ -1284,6 +1346,7 @@ void rt_destroy(rt_handle h) {
     hipSetDevice(h->device);
     free_scene(h);
     free_pipeline(h);
+    hipFree(h->d_bloom[0]); hipFree(h->d_bloom[1]); hipFree(h->d_bloom_kern);
     hipFree(h->d_ctrl); hipFree(h->d_rgb); hipFree(h->d_hits); hipFree(h->d_stream_rays);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1808,6 +1871,51 @@ static int render_host(rt_handle h, int stream_mode, double* rgb, uint64_t* rays
 int rt_render(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { return render_host(h, 0, rgb, rays, hit_ids); }
 
 int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { return render_host(h, 1, rgb, rays, hit_ids); }
+
+int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
+                     int32_t* d_img, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!d_rgb || !d_img || width < 1 || height < 1 || num_blurs < 0) return fail(h, RT_ERR_ARG, "rt_expose_device: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)width * height;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
+    if (num_blurs == 0) {
+        hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)nullptr, d_img, n, exposure);
+        HIP_TRY(h, hipGetLastError());
+        return RT_OK;
+    }
+    if (!h->d_bloom_kern) {
+        // the Gaussian of main.cpp:188-194, evaluated on the host with the C library's exp like the reference
+        const double stddev = 3, denom = 2 * stddev * stddev;
+        std::vector<double> k((size_t)BLOOM_K * BLOOM_K);
+        for (int y = -BLOOM_R; y <= BLOOM_R; y++)
+            for (int x = -BLOOM_R; x <= BLOOM_R; x++)
+                k[(size_t)(y + BLOOM_R) * BLOOM_K + x + BLOOM_R] = exp(-(x * x + y * y) / denom) / denom / M_PI;
+        HIP_TRY(h, hipMalloc((void**)&h->d_bloom_kern, k.size() * sizeof(double)));
+        HIP_TRY(h, hipMemcpy(h->d_bloom_kern, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h->bloom_doubles < n * 3) {
+        for (int q = 0; q < 2; q++) { hipFree(h->d_bloom[q]); h->d_bloom[q] = nullptr; }
+        h->bloom_doubles = 0;
+        for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->d_bloom[q], n * 3 * sizeof(double)));
+        h->bloom_doubles = n * 3;
+    }
+    unsigned g3 = (unsigned)((n * 3 + 255) / 256);
+    if (g3 > (unsigned)h->cu_count * 32u) g3 = (unsigned)h->cu_count * 32u;
+    hipLaunchKernelGGL(expose_mask_kernel, dim3(g3), dim3(256), 0, st, d_rgb, h->d_bloom[0], n * 3, exposure);
+    int cur = 0;
+    const dim3 bgrid((width + BLOOM_T - 1) / BLOOM_T, (height + BLOOM_T - 1) / BLOOM_T, 3);
+    for (int b = 0; b < num_blurs; b++) {
+        hipLaunchKernelGGL(bloom_kernel, bgrid, dim3(BLOOM_T * BLOOM_T), 0, st, (const double*)h->d_bloom[cur], h->d_bloom[cur ^ 1],
+                           width, height, (const double*)h->d_bloom_kern);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)h->d_bloom[cur], d_img, n, exposure);
+    HIP_TRY(h, hipGetLastError());
+    return RT_OK;
+}
 
 int rt_last_timing(rt_handle h, rt_timing* out) {
     if (!h || !out) return RT_ERR_ARG;

@@ -1,0 +1,64 @@
+"""GPU parity of expose() on the device (rt_expose_device: bloom + Color::to_int pack,
+/root/reference/src/main.cpp:186-242, src/geometry.cpp:15-23) against the CPU oracle's expose, which the
+golden tests pin to the compiled reference.  Bar: every packed pixel equal (integer output)."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from raytracer_amd import api, scene as S
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _expose_gpu(renderer, rgb, exposure, blurs):
+    H, W, _ = rgb.shape
+    d_rgb = torch.from_numpy(np.ascontiguousarray(rgb)).to("cuda:0")
+    d_img = torch.full((H, W), -7, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    renderer.expose_device(d_rgb.data_ptr(), W, H, exposure, blurs, d_img.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d_rgb.cpu(), torch.from_numpy(np.ascontiguousarray(rgb))) or np.isnan(rgb).any()   # input untouched
+    return d_img.cpu().numpy()
+
+
+@pytest.mark.parametrize("blurs", [0, 1, 3])
+def test_expose_scene_json_frame(renderer, golden_dir, blurs):
+    """A real frame (scene.json rendered on the GPU; 41.6 % of its pixels saturate, so the bloom is busy)."""
+    sc = S.read_json_scene(os.path.join(golden_dir, "scene.json"))
+    renderer.upload(sc)
+    rgb = renderer.render()["rgb"]
+    want, _ = po.expose(rgb, sc.header["exposure"], blurs)
+    got = _expose_gpu(renderer, rgb, sc.header["exposure"], blurs)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} packed pixels differ"
+    assert np.array_equal(got, api.expose(rgb, sc.header["exposure"], blurs))     # and the numpy host mirror
+
+
+@pytest.mark.parametrize("shape,exposure,blurs", [((1, 1), 1.0, 2), ((7, 301), 0.5, 1), ((45, 16), 2.0, 2), ((33, 47), 1.3, 0),
+                                                  ((130, 70), 0.7, 3)])
+def test_expose_ragged_frames_and_edge_values(renderer, shape, exposure, blurs):
+    """Frames smaller than the bloom radius, not multiples of the tile, with the values Color::to_int meets at its
+    edges: negative, just below/above an integer step, huge, infinite, NaN (converted as x86 does: INT_MIN)."""
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    rgb = rng.uniform(0, 2.0 / exposure, (H, W, 3))
+    flat = rgb.reshape(-1)
+    special = np.array([0.0, -0.0, -0.3, 1.0 / exposure, np.nextafter(1.0 / exposure, 0), np.nextafter(1.0 / exposure, 9),
+                        1e300, -1e300, np.inf, -np.inf, np.nan, 3e9, -3e9, 1e-320, 254.999999 / 255 / exposure])
+    idx = rng.choice(flat.size, size=min(flat.size, special.size), replace=False)
+    flat[idx] = special[: idx.size]
+    want, _ = po.expose(rgb, exposure, blurs)
+    got = _expose_gpu(renderer, rgb, exposure, blurs)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} packed pixels differ"
+
+
+def test_expose_rows_before_gather(renderer):
+    """num_blurs = 0: exposing a rank's packed rows gives the same pixels as exposing the whole frame."""
+    rng = np.random.default_rng(9)
+    rgb = rng.uniform(0, 3, (64, 50, 3))
+    whole = _expose_gpu(renderer, rgb, 0.8, 0)
+    rows = np.r_[8:16, 40:48]
+    part = _expose_gpu(renderer, rgb[rows], 0.8, 0)
+    assert np.array_equal(part, whole[rows])
