@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W            (N = 1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-One step = one frame of the workload: every rank renders its cyclic row tiles of the SAME
-frame (scene tables already resident in HBM), the tiles are gathered to rank 0 (RCCL) and
-de-interleaved there.  The frame is fixed, so scaling over N is strong scaling.
+One step = one frame of the workload as the reference's main() times it (render + expose):
+every rank renders its cyclic row tiles of the SAME frame (scene tables already resident in
+HBM), packs them to 8-bit pixels (Color::to_int; the timing scenes have num_blurs = 0), and
+the packed rows are gathered to rank 0 (RCCL) and de-interleaved there.  The frame is fixed,
+so scaling over N is strong scaling.
 
 Prints ONE JSON line on rank 0: Mrays/s (whole job), ms per frame, the FP32-VALU roofline
 figure of the render kernel (algorithmic FLOP of the closest-hit scan / kernel time, HIP
@@ -29,7 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracer_amd import api, synth  # noqa: E402
-from raytracer_amd.dist import FrameGatherer, sum_over_ranks  # noqa: E402
+from raytracer_amd.dist import FramePipeline, sum_over_ranks  # noqa: E402
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32, FMA = 2 FLOP
 
@@ -107,27 +109,37 @@ def main():
     ren.set_option(api.OPT_TIMING_DETAIL, 1)     # HIP events around every broad_kernel launch
     ren.upload(sc)
     H, W = sc.height, sc.width
-    gat = FrameGatherer(H, W, 3, args.tile_rows, rank, world, device)
     stream = torch.cuda.current_stream(device)
+    exposure, blurs = float(sc.header["exposure"]), int(sc.header["num_blurs"])
+    ev = []          # (start, end) HIP events around the render kernels of every timed frame, on the launch stream
+    timed = [False]
 
-    def step():
-        ren.render_rows_device(gat.local.data_ptr(), args.tile_rows, rank, world, stream=stream.cuda_stream)
-        return gat.gather()
+    def render_rows(dst):
+        if timed[0]:
+            ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            ev[-1][0].record(stream)
+        ren.render_rows_device(dst.data_ptr(), args.tile_rows, rank, world, stream=stream.cuda_stream)
+        if timed[0]:
+            ev[-1][1].record(stream)
+
+    def expose(src, rows, dst, nb):
+        ren.expose_device(src.data_ptr(), W, rows, exposure, nb, dst.data_ptr(), stream=stream.cuda_stream)
+
+    # one step = one frame as main() times it (main.cpp:305-315): render, expose (8-bit pack; the timing scenes have
+    # num_blurs = 0), and the gather of the packed rows to rank 0
+    pipe = FramePipeline(H, W, blurs, args.tile_rows, rank, world, device, render_rows, expose)
 
     for _ in range(args.warmup):
-        step()
+        pipe.step()
         ren.finish()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    timed[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record(stream)
-        ren.render_rows_device(gat.local.data_ptr(), args.tile_rows, rank, world, stream=stream.cuda_stream)
-        ev[i][1].record(stream)
-        frame = gat.gather()
+        frame = pipe.step()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -157,7 +169,8 @@ def main():
             "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
-                       "partition": f"cyclic row tiles over {world} GPU(s), gather to rank 0"},
+                       "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",
+                       "step": "render + expose (num_blurs %d) + gather" % blurs},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                          "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,

@@ -67,6 +67,45 @@ class FrameGatherer:
         return self.frame
 
 
+class FramePipeline:
+    """render -> expose -> gather, the sequence main() times (main.cpp:305-315), over the ranks of one node.
+
+    num_blurs == 0 (every timing configuration): Color::to_int works pixel by pixel, so each rank packs the rows it
+    rendered and the gather moves 4 bytes per pixel instead of 24.  num_blurs > 0: the bloom reads 20 rows either
+    side of a pixel per pass, so the radiance rows are gathered and rank 0 exposes the whole frame.
+
+    render_rows(dst): fill dst[:my_rows] (float64 [rows, W*3]) with this rank's rows, in stream order.
+    expose(src, rows, dst, num_blurs): pack src (float64 [rows, W*3]) into dst (int32 [rows, W]), in stream order.
+    On a GPU both are thin wrappers of rt_render_rows_device / rt_expose_device; the CPU tests pass oracle stand-ins.
+    """
+
+    def __init__(self, height, width, num_blurs, tile_rows, rank, world, device, render_rows, expose):
+        self.h, self.w, self.blurs = height, width, int(num_blurs)
+        self.rank, self.world = rank, world
+        self.render_rows, self.expose = render_rows, expose
+        self.n_mine = len(rows_of_rank(height, tile_rows, rank, world))
+        if self.blurs == 0:
+            self.rad = torch.empty((max_rows(height, tile_rows, world), width * 3), dtype=torch.float64, device=device)
+            self.gat = FrameGatherer(height, width, 1, tile_rows, rank, world, device, dtype=torch.int32)
+        else:
+            self.gat = FrameGatherer(height, width, 3, tile_rows, rank, world, device, dtype=torch.float64)
+            self.rad = self.gat.local
+            self.img = torch.empty((height, width), dtype=torch.int32, device=device) if rank == 0 else None
+
+    def step(self):
+        """One frame.  Collective.  Returns the packed frame int32[H, W] on rank 0, None elsewhere."""
+        self.render_rows(self.rad)
+        if self.blurs == 0:
+            if self.n_mine:
+                self.expose(self.rad, self.n_mine, self.gat.local, 0)
+            return self.gat.gather()
+        frame = self.gat.gather()
+        if self.rank != 0:
+            return None
+        self.expose(frame, self.h, self.img, self.blurs)
+        return self.img
+
+
 def sum_over_ranks(value: int, device, world: int) -> int:
     """Ray counters: the reference sums long num_rays[T] (main.cpp:321-324); here one all-reduce."""
     if world == 1:

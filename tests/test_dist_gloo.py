@@ -37,6 +37,50 @@ def _worker(rank, world, port, tile_rows, out_path):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, tile_rows, blurs, out_path):
+    """render -> expose -> gather (FramePipeline) with the oracle standing in for both device calls."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from raytracer_amd import synth
+    from raytracer_amd.dist import FramePipeline, rows_of_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, sc = synth.make("c2", width=64)
+    H, W = sc.height, sc.width
+    exposure = float(sc.header["exposure"]) * 3.0     # brighter: part of the frame saturates, so the bloom has input
+    mine = rows_of_rank(H, tile_rows, rank, world).numpy()
+    full = po.render(sc, policy=po.POLICY_DEV, rng_mode=po.RNG_PIXEL, workers=2)
+
+    def render_rows(dst):
+        dst.zero_()
+        dst[: len(mine)] = torch.from_numpy(full["rgb"][mine].reshape(len(mine), W * 3))
+
+    def expose(src, rows, dst, nb):
+        img, _ = po.expose(src[:rows].numpy().reshape(rows, W, 3), exposure, nb, workers=2)
+        dst[:rows] = torch.from_numpy(img)
+
+    pipe = FramePipeline(H, W, blurs, tile_rows, rank, world, torch.device("cpu"), render_rows, expose)
+    got = pipe.step()
+    got = pipe.step()                                  # buffers are reused frame after frame
+    if rank == 0:
+        want, _ = po.expose(full["rgb"], exposure, blurs, workers=2)
+        ok = np.array_equal(got.numpy().reshape(H, W), want) and len(np.unique(want)) > 10
+        open(out_path, "w").write(str(int(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tile_rows,blurs", [(8, 0), (5, 0), (8, 1)])
+def test_two_rank_render_expose_gather(tmp_path, tile_rows, blurs):
+    """Packed 8-bit rows gathered (num_blurs = 0) and radiance rows gathered + rank-0 bloom (num_blurs > 0) both
+    give the single-process frame."""
+    out = str(tmp_path / "res.txt")
+    port = 31500 + (os.getpid() % 2000) + tile_rows + 16 * blurs
+    mp.spawn(_pipeline_worker, args=(2, port, tile_rows, blurs, out), nprocs=2, join=True)
+    assert open(out).read() == "1"
+
+
 @pytest.mark.parametrize("tile_rows", [1, 8])
 def test_two_rank_gather_equals_single_frame(tmp_path, tile_rows):
     out = str(tmp_path / "res.txt")
