@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--width", type=int, default=None, help="override the frame width (height follows 16:9)")
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-frames", type=int, default=3, help="untimed frames with per-launch kernel timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +107,6 @@ def main():
 
     _, sc = synth.make(args.workload, width=args.width)
     ren = api.Renderer(local_rank)
-    ren.set_option(api.OPT_TIMING_DETAIL, 1)     # HIP events around every broad_kernel launch
     ren.upload(sc)
     H, W = sc.height, sc.width
     stream = torch.cuda.current_stream(device)
@@ -146,9 +146,24 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     rays_local = ren.finish()                     # counters of the last frame; every step renders the same frame
-    tm = ren.timing()
     frame_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # all kernels of one frame on this GPU
-    broad_ms = tm["broad_ms"] if tm["broad_ms"] > 0 else tm["kernel_ms"]       # the dominant kernel's launches, last frame
+    # Roofline of the dominant kernel, outside the timed region: a few more frames with HIP events around every
+    # broad_kernel launch on its launch stream.  Per-launch timing makes the library run the kernels one after the
+    # other (in the timed frames the broad phase of one half-frame overlaps the shading of the other, and a launch's
+    # duration would include the time it shares its CUs).
+    timed[0] = False
+    ren.set_option(api.OPT_TIMING_DETAIL, 1)
+    broad, serial = [], []
+    for _ in range(args.roofline_frames):
+        pipe.step()
+        ren.finish()
+        tm = ren.timing()
+        broad.append(tm["broad_ms"] if tm["broad_ms"] > 0 else tm["kernel_ms"])
+        serial.append(tm["kernel_ms"])
+    if not broad:                                 # --roofline-frames 0 (counter passes): no per-launch timing
+        tm = ren.timing()
+        broad, serial = [tm["kernel_ms"]], [tm["kernel_ms"]]
+    broad_ms, serial_ms = float(np.mean(broad)), float(np.mean(serial))
 
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -176,7 +191,7 @@ def main():
                          "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,
                          "traffic_unit": "HBM bytes per frame (all broad_kernel launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE",
                          "kernel": "broad_kernel (all launches of one frame)", "kernel_ms": broad_ms,
-                         "frame_kernels_ms": frame_kernels_ms,
+                         "frame_kernels_ms": frame_kernels_ms, "frame_kernels_serial_ms": serial_ms,
                          "frac_whole_frame": flops_local / (frame_kernels_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
                          "rays_this_gpu": rays_local, "candidates_per_ray": tm["candidates"] / max(1, tm["rays"]),
                          "overflow_rays": tm.get("overflow_rays", 0)},
