@@ -18,7 +18,9 @@
 #include <stdint.h>
 
 #define RTM_FN __host__ __device__ __forceinline__
+#ifndef RTM_BIG
 #define RTM_BIG __host__ __device__ __attribute__((noinline))
+#endif
 
 namespace rtm {
 
