@@ -184,6 +184,15 @@ int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids
 int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
                      int32_t* d_img, void* stream);
 
+/* Convenience: the whole of main()'s timed section on this device -- render every pixel, expose() with the exposure
+ * and num_blurs of the uploaded scene header -- with only the packed image copied to the HOST (4 bytes per pixel
+ * instead of the 24 of the radiance array).
+ *   reference_order : 0 = one RNG stream per pixel; 1 = the reference's order (one lane per reference thread)
+ *   img  : int32[height*width], what writeImage takes (pngUtil.c:4)
+ *   rays : out, ray segments traced
+ * Replaces main.cpp:304-314 (thread fan-out around do_rays_i, join, expose). */
+int rt_render_image(rt_handle h, int reference_order, int32_t* img, uint64_t* rays);
+
 /* Timing and work counters of the last upload/render (HIP-event device time). */
 int rt_last_timing(rt_handle h, rt_timing* out);
 

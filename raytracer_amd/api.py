@@ -26,7 +26,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
           -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
-           "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device",
+           "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
 
 
@@ -78,6 +78,8 @@ def load_library(path: str = LIB_PATH):
         f.argtypes = [C.c_void_p, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     l.rt_expose_device.restype = C.c_int
     l.rt_expose_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    l.rt_render_image.restype = C.c_int
+    l.rt_render_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     l.rt_last_timing.restype = C.c_int
     l.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(RtTiming)]
     l.rt_last_error.restype = C.c_char_p
@@ -156,6 +158,16 @@ class Renderer:
             self._check(self.lib.rt_stream_rays(self.h, sr.ctypes.data_as(C.POINTER(C.c_uint64)), T))
             out["stream_rays"] = sr
         return out
+
+    def render_image(self, streams=False):
+        """Render + expose on the device, packed frame on the host: dict(img=int32[H,W], rays=int)."""
+        sc = self.scene
+        if sc is None:
+            raise RtError(-3, "no scene uploaded")
+        img = np.zeros((sc.height, sc.width), dtype=np.int32)
+        rays = C.c_uint64(0)
+        self._check(self.lib.rt_render_image(self.h, 1 if streams else 0, img.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(rays)))
+        return dict(img=img, rays=int(rays.value))
 
     def render_rows_device(self, d_rgb_ptr, tile_rows, rank, world, d_hits_ptr=None, stream=None):
         """Asynchronous render of this rank's row tiles into device memory (raw pointers)."""

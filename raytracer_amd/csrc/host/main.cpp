@@ -3,10 +3,11 @@
 // print "Time:" and "Rays:", write the PNG -- and the same defaults (./scene.json -> ./test.png); the
 // paths and a few switches come from argv, which the reference does not read.
 //
-//   rt_main [scene.json] [out.png] [--device N] [--reference-order] [--dump-tables file] [--no-render]
+//   rt_main [scene.json] [out.png] [--device N] [--reference-order] [--host-expose] [--dump-tables file] [--no-render]
 //
 // --reference-order renders with one GPU lane per reference thread in the reference's RNG order
-// (validation mode: the 8-bit image then equals the reference binary's).
+// (validation mode: the 8-bit image then equals the reference binary's).  expose() runs on the device and only the
+// packed image comes back; --host-expose copies the radiance array back and runs the C++ expose() instead.
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -19,13 +20,14 @@
 int main(int argc, char** argv) {
     std::string scene_path = "scene.json", out_path = "test.png", dump_path;
     int device = 0;
-    bool ref_order = false, no_render = false;
+    bool ref_order = false, no_render = false, host_expose = false;
     int pos = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--reference-order") ref_order = true;
         else if (a == "--no-render") no_render = true;
+        else if (a == "--host-expose") host_expose = true;
         else if (a == "--dump-tables" && i + 1 < argc) dump_path = argv[++i];
         else if (pos == 0) { scene_path = a; pos++; }
         else if (pos == 1) { out_path = a; pos++; }
@@ -63,14 +65,19 @@ int main(int argc, char** argv) {
     if (rc != RT_OK) { fprintf(stderr, "rt_main: rt_create failed (%d): no usable GPU\n", rc); return 1; }
     rc = rt_upload_scene(h, sc.params.data(), sc.n_prims(), sc.prims.data(), sc.n_mats(), sc.mats.data(), sc.n_verts(), sc.verts.data());
     if (rc != RT_OK) { fprintf(stderr, "rt_main: %s\n", rt_last_error(h)); rt_destroy(h); return 1; }
-    std::vector<double> colors((size_t)W * H * 3);
     std::vector<int> img((size_t)W * H);
     uint64_t rays = 0;
     auto start = std::chrono::system_clock::now();
-    rc = ref_order ? rt_render_streams(h, colors.data(), &rays, nullptr) : rt_render(h, colors.data(), &rays, nullptr);
-    if (rc != RT_OK) { fprintf(stderr, "rt_main: %s\n", rt_last_error(h)); rt_destroy(h); return 1; }
-    unsigned hw = std::thread::hardware_concurrency();
-    rt::expose(img.data(), colors.data(), W, H, sc.exposure(), sc.num_blurs(), hw ? (int)hw : 1);
+    if (host_expose) {
+        std::vector<double> colors((size_t)W * H * 3);
+        rc = ref_order ? rt_render_streams(h, colors.data(), &rays, nullptr) : rt_render(h, colors.data(), &rays, nullptr);
+        if (rc != RT_OK) { fprintf(stderr, "rt_main: %s\n", rt_last_error(h)); rt_destroy(h); return 1; }
+        unsigned hw = std::thread::hardware_concurrency();
+        rt::expose(img.data(), colors.data(), W, H, sc.exposure(), sc.num_blurs(), hw ? (int)hw : 1);
+    } else {
+        rc = rt_render_image(h, ref_order ? 1 : 0, img.data(), &rays);
+        if (rc != RT_OK) { fprintf(stderr, "rt_main: %s\n", rt_last_error(h)); rt_destroy(h); return 1; }
+    }
     auto end = std::chrono::system_clock::now();
     std::chrono::duration<double> elapsed = end - start;
     double sec = elapsed.count();

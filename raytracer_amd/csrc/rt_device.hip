@@ -1095,7 +1095,8 @@ struct rt_context {
     bool have_scene = false;
     // frame parameters
     int width = 0, height = 0, spp = 0, depth = 0, num_threads = 1;
-    double scale = 0, lens = 0, focal = 0;
+    double scale = 0, lens = 0, focal = 0, exposure = 1;
+    int num_blurs = 0;
     unsigned frame_seed = 0;
     int has_light = 0, light_draws = 0;
     bool regular_paths = false;   // every path ends within 2*depth+1 segments (an emitter exists, no index-1 glass)
@@ -1589,6 +1590,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     h->width = W; h->height = H; h->spp = spp; h->depth = depth;
     h->num_threads = (int)params[RT_PA_THREADS] > 0 ? (int)params[RT_PA_THREADS] : 1;
     h->scale = params[RT_PA_SCALE]; h->lens = params[RT_PA_LENS]; h->focal = params[RT_PA_FOCAL];
+    h->exposure = params[RT_PA_EXPOSURE]; h->num_blurs = (int)params[RT_PA_BLURS] > 0 ? (int)params[RT_PA_BLURS] : 0;
     h->frame_seed = (unsigned)params[RT_PA_SEED];
     h->has_light = first_light >= 0;
     h->light_draws = 0;
@@ -1934,6 +1936,25 @@ int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, do
     }
     hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)h->d_bloom[cur], d_img, n, exposure);
     HIP_TRY(h, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_image(rt_handle h, int reference_order, int32_t* img, uint64_t* rays) {
+    if (!h) return RT_ERR_ARG;
+    if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render_image: no scene uploaded");
+    if (!img) return fail(h, RT_ERR_ARG, "rt_render_image: img is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t npx = (size_t)h->width * h->height;
+    const size_t rb = npx * 3 * sizeof(double), ib = npx * sizeof(int32_t);
+    if (h->d_rgb_bytes < rb) { hipFree(h->d_rgb); h->d_rgb = nullptr; h->d_rgb_bytes = 0; HIP_TRY(h, hipMalloc((void**)&h->d_rgb, rb)); h->d_rgb_bytes = rb; }
+    if (h->d_hits_bytes < ib) { hipFree(h->d_hits); h->d_hits = nullptr; h->d_hits_bytes = 0; HIP_TRY(h, hipMalloc((void**)&h->d_hits, ib)); h->d_hits_bytes = ib; }
+    int rc = render_common(h, reference_order ? 1 : 0, h->height, 0, 1, h->d_rgb, nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    rc = rt_finish(h, rays);
+    if (rc != RT_OK) return rc;
+    rc = rt_expose_device(h, h->d_rgb, h->width, h->height, h->exposure, h->num_blurs, h->d_hits, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipMemcpy(img, h->d_hits, ib, hipMemcpyDeviceToHost));   // the packed image borrows the hit-id scratch buffer
     return RT_OK;
 }
 

@@ -62,3 +62,34 @@ def test_expose_rows_before_gather(renderer):
     rows = np.r_[8:16, 40:48]
     part = _expose_gpu(renderer, rgb[rows], 0.8, 0)
     assert np.array_equal(part, whole[rows])
+
+
+def test_render_image_equals_render_then_expose(renderer, golden_dir):
+    """rt_render_image (render + device expose, packed frame to the host) against the two-step path, bloom included."""
+    sc = S.read_json_scene(os.path.join(golden_dir, "small_room.scene.json"))
+    renderer.upload(sc)
+    g = renderer.render()
+    want, _ = po.expose(g["rgb"], sc.header["exposure"], sc.header["num_blurs"])
+    got = renderer.render_image()
+    assert got["rays"] == g["rays"]
+    assert np.array_equal(got["img"], want)
+
+
+@pytest.mark.parametrize("flags", [[], ["--host-expose"]])
+def test_rt_main_writes_the_reference_image(golden_dir, tmp_path, flags):
+    """The C++ host program end to end: scene.json -> PNG in the reference's RNG order (num_threads = 4, 3 bloom
+    passes) must decode to the golden pixels of the compiled reference, with expose() on the device and on the host."""
+    import json
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(api.HERE), "raytracer_amd", "rt_main")
+    out = str(tmp_path / "test.png")
+    r = subprocess.run([exe, os.path.join(golden_dir, "scene.json"), out, "--reference-order"] + flags,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Time: " in r.stdout and "Rays: " in r.stdout
+    gold = [e for e in json.load(open(os.path.join(golden_dir, "golden.json")))
+            if e["scene"] == "scene.json" and e["threads"] == 4 and e["blurs"] == 3][0]
+    ref8 = np.load(os.path.join(golden_dir, gold["pixels"]))["rgb8"]
+    got8 = np.array(Image.open(out).convert("RGB"))
+    assert np.array_equal(got8, ref8)
