@@ -1011,18 +1011,25 @@ __global__ __launch_bounds__(BLOOM_T * BLOOM_T) void bloom_kernel(const double* 
     __shared__ double tile[BLOOM_TILE][BLOOM_TILE + 1];
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * BLOOM_T - BLOOM_R, y0 = blockIdx.y * BLOOM_T - BLOOM_R;
+    bool lit = false;
     for (int i = threadIdx.x; i < BLOOM_TILE * BLOOM_TILE; i += BLOOM_T * BLOOM_T) {
         const int ty = i / BLOOM_TILE, tx = i - ty * BLOOM_TILE;
         const int x = x0 + tx, y = y0 + ty;
-        tile[ty][tx] = (x >= 0 && x < W && y >= 0 && y < H) ? src[((size_t)y * W + x) * 3 + ch] : 0.0;
+        const double v = (x >= 0 && x < W && y >= 0 && y < H) ? src[((size_t)y * W + x) * 3 + ch] : 0.0;
+        tile[ty][tx] = v;
+        lit |= (v != 0.0);
     }
-    __syncthreads();
+    // a tile without a lit source pixel (most of a frame: only emitters and highlights saturate) sums 1681 products
+    // +0.0 * k into +0.0; the barrier doubles as that test
+    const bool any_lit = __syncthreads_or(lit ? 1 : 0) != 0;
     const int lx = threadIdx.x % BLOOM_T, ly = threadIdx.x / BLOOM_T;
     double c = 0.0;
-    for (int ky = 0; ky < BLOOM_K; ky++) {
-        const double* krow = kern + ky * BLOOM_K;
-#pragma unroll 1
-        for (int kx = 0; kx < BLOOM_K; kx++) c = c + tile[ly + ky][lx + kx] * krow[kx];
+    if (any_lit) {
+        for (int ky = 0; ky < BLOOM_K; ky++) {
+            const double* krow = kern + ky * BLOOM_K;
+#pragma unroll
+            for (int kx = 0; kx < BLOOM_K; kx++) c = c + tile[ly + ky][lx + kx] * krow[kx];
+        }
     }
     const int x = blockIdx.x * BLOOM_T + lx, y = blockIdx.y * BLOOM_T + ly;
     if (x < W && y < H) dst[((size_t)y * W + x) * 3 + ch] = c;
