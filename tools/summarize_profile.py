@@ -29,7 +29,7 @@ m = re.search(r'\{"metric".*\}', log)
 frames = json.loads(m.group(0))['steps'] + json.loads(m.group(0))['warmup'] if m else None
 
 lines = ['# ' + prefix, '', 'bench line: `' + json.dumps({k: bench[k] for k in ('value', 'unit', 'ms_per_step', 'n_gpus')}) + '`',
-         '', '## rocprofv3 --kernel-trace --stats (%s frames traced)' % frames, '',
+         '', '## rocprofv3 --kernel-trace --stats (%s frames traced, RT_OVERLAP=1: kernels one after the other)' % frames, '',
          '| kernel | calls | avg us | total ms | ms per frame | % |', '|---|---|---|---|---|---|']
 for row in csv.DictReader(open(os.path.join(src, 'trace', 'vm_kernel_stats.csv'))):
     tot = float(row['TotalDurationNs']) / 1e6
@@ -46,12 +46,14 @@ for (k, c), v in sorted(ft.items()):
     traffic[k] = {'launches': fn[(k, c)], 'fetch_kb_raw': v, 'write_kb': w, 'bytes_per_frame': b}
     lines.append('| %s | %d | %.0f | %.0f | %.3e |' % (k, fn[(k, c)], v, w, b))
 st, sn = pmc('pmc_sq')
+st2, _ = pmc('pmc_sq2')
+st.update(st2)
 if st:
     lines += ['', '## SQ counters per frame', '', '| kernel | counter | total |', '|---|---|---|']
     for (k, c), v in sorted(st.items()):
         if 'rocclr' in k or k.startswith('at::'): continue
         lines.append('| %s | %s | %.4g |' % (k, c, v))
 open(os.path.join(dst, prefix + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
-json.dump({'source': prefix, 'note': 'HBM bytes per frame and kernel: (2 x FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes',
+json.dump({'source': prefix, 'workload': bench.get('config', {}).get('workload'), 'note': 'HBM bytes per frame and kernel: (2 x FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes',
            'kernels': traffic}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print('\n'.join(lines))
