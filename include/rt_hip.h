@@ -78,6 +78,7 @@ enum {
     RT_PA_WIDTH = 0, RT_PA_HEIGHT, RT_PA_SPP, RT_PA_DEPTH, RT_PA_THREADS, RT_PA_BLURS,
     RT_PA_SCALE, RT_PA_LENS, RT_PA_FOCAL, RT_PA_EXPOSURE,
     RT_PA_SEED,        /* frame seed mixed into every pixel's RNG seed (0 by default) */
+    RT_PA_CAM_X, RT_PA_CAM_Y, RT_PA_CAM_Z,   /* camera; the reference's constant is (0,0,40), main.cpp:16 */
     RT_PA_COUNT
 };
 

@@ -50,7 +50,8 @@ enum { PR_KIND = 0, PR_LIGHT, PR_MAT0, PR_MAT1, PR_VOFF, PR_VCNT, PR_A, PR_N = 9
 // material record (doubles), the fields of struct Material, src/geometry.hpp:18-29
 enum { MT_REF = 0, MT_LIGHT = 3, MT_GLOSS, MT_DIFF, MT_SPEC = 8, MT_SEXP = 11, MT_RDIFF, MT_RSPEC = 15, MT_RSEXP = 18, MT_RINDEX, MT_STRIDE = 20 };
 // params (doubles), the header object of the scene stream, src/readShape.cpp:31-42
-enum { PA_WIDTH = 0, PA_HEIGHT, PA_SPP, PA_DEPTH, PA_THREADS, PA_BLURS, PA_SCALE, PA_LENS, PA_FOCAL, PA_EXPOSURE, PA_SEED, PA_COUNT };
+enum { PA_WIDTH = 0, PA_HEIGHT, PA_SPP, PA_DEPTH, PA_THREADS, PA_BLURS, PA_SCALE, PA_LENS, PA_FOCAL, PA_EXPOSURE, PA_SEED,
+       PA_CAM_X, PA_CAM_Y, PA_CAM_Z, PA_COUNT };
 
 enum { RNG_STREAM = 0, RNG_PIXEL = 1 };
 
@@ -126,6 +127,7 @@ struct Tracer {
     int first_light = -1;
     int width = 0, height = 0, spp = 0, depth = 0;
     R scale = 0, lens = 0, focal = 0;
+    R cam[3] = {0, 0, 40};        // main.cpp:16
     uint32_t frame_seed = 0;
     bool guard_tripped = false;
     FILE* log = nullptr;          // when set, trace() prints one line per segment (debugging aid)
@@ -171,6 +173,7 @@ struct Tracer {
         spp = (int)params[PA_SPP]; depth = (int)params[PA_DEPTH];
         scale = (R)params[PA_SCALE]; lens = (R)params[PA_LENS]; focal = (R)params[PA_FOCAL];
         frame_seed = (uint32_t)params[PA_SEED];
+        for (int k = 0; k < 3; k++) cam[k] = (R)params[PA_CAM_X + k];
         mats.resize(s.n_mats);
         for (int i = 0; i < s.n_mats; i++) {
             const double* m = s.mats + (size_t)i * MT_STRIDE;
@@ -401,7 +404,7 @@ struct Tracer {
 
     // one pixel: the body of do_rays_i, src/main.cpp:252-275
     void pixel(int x, int y, Rng& g, long* rays, R out[3], int32_t* hit_ids) {
-        const V camera = mk(0, 0, 40);                                      // main.cpp:16
+        const V camera = mk(cam[0], cam[1], cam[2]);                        // main.cpp:16: (0,0,40) unless the header moves it
         const R PI = (R)M_PI;
         R acc[3] = {0, 0, 0};
         for (int i = 0; i < spp; i++) {

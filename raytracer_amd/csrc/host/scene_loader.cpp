@@ -169,6 +169,13 @@ SceneTables parse_scene_text(const std::string& text) {
     sc.params[RT_PA_FOCAL] = num(*head, "focal_length");
     sc.params[RT_PA_DEPTH] = num(*head, "max_ray_depth");
     sc.params[RT_PA_THREADS] = num(*head, "num_threads");
+    // optional extension: "camera": [x, y, z]; the reference's constant (main.cpp:16) otherwise
+    sc.params[RT_PA_CAM_X] = 0.0; sc.params[RT_PA_CAM_Y] = 0.0; sc.params[RT_PA_CAM_Z] = 40.0;
+    if (head->obj.find("camera") != head->obj.end()) {
+        double cam[3];
+        vec3(*head, "camera", cam);
+        for (int k = 0; k < 3; k++) sc.params[RT_PA_CAM_X + k] = cam[k];
+    }
     for (int i = 0; i < num_objs; i++) {
         if (p.at_end()) throw SceneError("header announces " + std::to_string(num_objs) + " objects, stream holds " + std::to_string(i));
         JPtr op = p.value();

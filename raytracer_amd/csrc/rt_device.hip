@@ -87,6 +87,7 @@ struct MatD {                // struct Material (geometry.hpp:18-29) in double
 struct KParams {
     int width, height, spp, depth;
     double scale, lens, focal;
+    double cam[3];           // camera, main.cpp:16
     unsigned frame_seed;
     int has_light, light_draws;
     int tile_rows, rank, world;
@@ -396,7 +397,7 @@ DEV void start_path(PathState& s, const KParams& kp) {
     double rad = rng_uniform(s.rng) * kp.lens;
     double st, ct;
     rtm::sincosd(theta, &st, &ct);
-    const d3 camera = dmk(0.0, 0.0, 40.0);
+    const d3 camera = dmk(kp.cam[0], kp.cam[1], kp.cam[2]);
     d3 org = dmk(camera.x + rad * ct, camera.y + rad * st, camera.z + 0.0);
     d3 D = dnorm(dsub(pix, camera));
     d3 C = dalong(camera, kp.focal, D);
@@ -1103,6 +1104,7 @@ struct rt_context {
     // frame parameters
     int width = 0, height = 0, spp = 0, depth = 0, num_threads = 1;
     double scale = 0, lens = 0, focal = 0, exposure = 1;
+    double cam[3] = {0, 0, 40};
     int num_blurs = 0;
     unsigned frame_seed = 0;
     int has_light = 0, light_draws = 0;
@@ -1209,6 +1211,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     memset(&kp, 0, sizeof(kp));
     kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
     kp.scale = h->scale; kp.lens = h->lens; kp.focal = h->focal; kp.frame_seed = h->frame_seed;
+    for (int k = 0; k < 3; k++) kp.cam[k] = h->cam[k];
     kp.has_light = h->has_light; kp.light_draws = h->light_draws;
     kp.tile_rows = 1; kp.rank = 0; kp.world = 1;
     kp.nchunks = h->nchunks;
@@ -1597,6 +1600,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     h->width = W; h->height = H; h->spp = spp; h->depth = depth;
     h->num_threads = (int)params[RT_PA_THREADS] > 0 ? (int)params[RT_PA_THREADS] : 1;
     h->scale = params[RT_PA_SCALE]; h->lens = params[RT_PA_LENS]; h->focal = params[RT_PA_FOCAL];
+    for (int k = 0; k < 3; k++) h->cam[k] = params[RT_PA_CAM_X + k];
     h->exposure = params[RT_PA_EXPOSURE]; h->num_blurs = (int)params[RT_PA_BLURS] > 0 ? (int)params[RT_PA_BLURS] : 0;
     h->frame_seed = (unsigned)params[RT_PA_SEED];
     h->has_light = first_light >= 0;

@@ -27,7 +27,9 @@ PR_KIND, PR_LIGHT, PR_MAT0, PR_MAT1, PR_VOFF, PR_VCNT, PR_A, PR_N, PR_RADIUS, PR
 # material record layout
 MT_REF, MT_LIGHT, MT_GLOSS, MT_DIFF, MT_SPEC, MT_SEXP, MT_RDIFF, MT_RSPEC, MT_RSEXP, MT_RINDEX, MT_STRIDE = 0, 3, 4, 5, 8, 11, 12, 15, 18, 19, 20
 # parameter vector layout
-PA_WIDTH, PA_HEIGHT, PA_SPP, PA_DEPTH, PA_THREADS, PA_BLURS, PA_SCALE, PA_LENS, PA_FOCAL, PA_EXPOSURE, PA_SEED, PA_COUNT = range(12)
+(PA_WIDTH, PA_HEIGHT, PA_SPP, PA_DEPTH, PA_THREADS, PA_BLURS, PA_SCALE, PA_LENS, PA_FOCAL, PA_EXPOSURE, PA_SEED,
+ PA_CAM_X, PA_CAM_Y, PA_CAM_Z, PA_COUNT) = range(15)
+DEFAULT_CAMERA = (0.0, 0.0, 40.0)      # Point camera(0,0,40), /root/reference/src/main.cpp:16
 
 HEADER_KEYS = ("exposure", "num_blurs", "num_objs", "paths_per_pixel", "width", "height", "scale",
                "lens_radius", "focal_length", "max_ray_depth", "num_threads")
@@ -64,6 +66,8 @@ class Scene:
         p[PA_DEPTH] = h["max_ray_depth"]; p[PA_THREADS] = h["num_threads"]; p[PA_BLURS] = h["num_blurs"]
         p[PA_SCALE] = h["scale"]; p[PA_LENS] = h["lens_radius"]; p[PA_FOCAL] = h["focal_length"]
         p[PA_EXPOSURE] = h["exposure"]; p[PA_SEED] = self.frame_seed
+        # optional header key "camera": [x, y, z] (an extension; the reference ignores unknown keys and uses its constant)
+        p[PA_CAM_X:PA_CAM_Z + 1] = h.get("camera", DEFAULT_CAMERA)
         return p
 
     def counts(self):
@@ -203,6 +207,8 @@ def from_objects(header: dict, objects: list, frame_seed: int = 0) -> Scene:
             mats.append(m)
         prims.append(p)
     sc = Scene(header={k: header[k] for k in HEADER_KEYS}, frame_seed=frame_seed)
+    if "camera" in header:
+        sc.header["camera"] = _vec3(header, "camera")
     sc.prims = np.ascontiguousarray(np.array(prims, dtype=np.float64).reshape(-1, PR_STRIDE))
     sc.mats = np.ascontiguousarray(np.array(mats, dtype=np.float64).reshape(-1, MT_STRIDE))
     sc.verts = np.ascontiguousarray(np.array(verts, dtype=np.float64).reshape(-1, 3))

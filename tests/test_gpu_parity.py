@@ -150,3 +150,14 @@ def test_single_kernel_and_pipeline_agree(renderer):
 def test_baseline_configs_reduced(renderer, cfg, width, kw):
     _, sc = synth.make(cfg, width=width, **kw)
     _compare(renderer, sc, cfg)
+
+
+def test_moved_camera_matches_oracle(renderer, golden_dir):
+    """Header extension "camera": the device and the oracle read the same three parameters (the reference's constant
+    (0,0,40) is their default); no reference output exists for a moved camera, so this case is pinned by the oracle only."""
+    text = open(os.path.join(golden_dir, "small_room.scene.json")).read()
+    sc = S.loads(text.replace('{"num_threads"', '{"camera": [3, -2.5, 45], "num_threads"', 1))
+    g, o = _compare(renderer, sc, "small_room[camera]")
+    base = S.loads(text)
+    renderer.upload(base)
+    assert not np.array_equal(renderer.render()["rgb"], g["rgb"])       # the key has an effect

@@ -61,6 +61,19 @@ def test_cpp_loader_equals_python_loader(golden_dir, name, tmp_path):
     assert np.array_equal(verts.view(np.uint64), sc.verts.ravel().view(np.uint64))
 
 
+def test_camera_header_key_is_optional_and_read_by_both_loaders(golden_dir, tmp_path):
+    """Extension of the scene format: "camera": [x, y, z] in the header; default = the reference's (0,0,40)."""
+    text = open(os.path.join(golden_dir, "small_room.scene.json")).read()
+    assert S.loads(text).params()[S.PA_CAM_X:S.PA_CAM_Z + 1].tolist() == [0.0, 0.0, 40.0]
+    moved = text.replace('{"num_threads"', '{"camera": [3, -2.5, 45], "num_threads"', 1)
+    sc = S.loads(moved)
+    assert sc.params()[S.PA_CAM_X:S.PA_CAM_Z + 1].tolist() == [3.0, -2.5, 45.0]
+    dst = str(tmp_path / "moved.json")
+    open(dst, "w").write(moved)
+    params = _dump_tables(dst)[0]
+    assert np.array_equal(params.view(np.uint64), sc.params().view(np.uint64))
+
+
 def test_scene_errors():
     with pytest.raises(S.SceneError):
         S.loads("")
