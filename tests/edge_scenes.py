@@ -1,0 +1,76 @@
+"""Small scenes around the edges of the scene format and of the path logic
+(/root/reference/src/readShape.cpp:26-122, src/main.cpp:126-183): empty list, no emitter, every emitter kind,
+triangles and pentagons, a face that is neither planar nor convex, a solid larger than the room, glass of index 1,
+depth 0 and the maximum depth, 1x1 and odd frame sizes.  Surfaces that can be met from behind are purely diffuse
+(a glossy one makes the reference's rejection loop spin, main.cpp:61-76).  Used by the GPU parity test, by the test
+that runs the compiled reference on them, and by tests/golden/make_golden.py."""
+import json
+
+DIFF = dict(diffuse=[0.7, 0.6, 0.5], specular=[0, 0, 0], specular_exp=1)
+
+
+def _header(n, width=48, height=27, spp=2, depth=3, lens=0.5, **kw):
+    h = dict(num_threads=4, num_objs=n, exposure=1, num_blurs=0, paths_per_pixel=spp, max_ray_depth=depth,
+             scale=width / 40.0, width=width, height=height, lens_radius=lens, focal_length=60)
+    h.update(kw)
+    return h
+
+
+def _sphere(c, r, light=False, glass=None, **mat):
+    o = dict(shape="sphere", is_light=light, center=list(c), radius=r)
+    if light:
+        o["color"] = [4, 3, 2]
+    else:
+        m = dict(DIFF, **mat)
+        o.update(diffuse=m["diffuse"], specular=m["specular"], specular_exp=m["specular_exp"],
+                 refraction_diffuse=[0.9, 0.9, 0.9], refraction_specular=[0, 0, 0], refraction_specular_exp=1,
+                 refraction_index=0 if glass is None else glass)
+    return o
+
+
+def _face(verts, normal, light=False, **mat):
+    o = dict(shape="face", is_light=light, normal=list(normal), verts=[list(v) for v in verts])
+    if light:
+        o["color"] = [5, 5, 4]
+    else:
+        o.update(dict(DIFF, **mat))
+    return o
+
+
+def _plane(point, normal, light=False):
+    return dict(shape="plane", is_light=light, point=list(point), normal=list(normal), diffuse1=[0.8, 0.8, 0.8],
+                diffuse2=[0.2, 0.3, 0.2], specular1=[0, 0, 0], specular2=[0, 0, 0], specular_exp=1)
+
+
+FLOOR = _plane((0, -12, 0), (0, 1, 0))
+CEIL_LIGHT = _face([(-15, 14, -30), (15, 14, -30), (15, 14, 5), (-15, 14, 5)], (0, -1, 0), light=True)
+
+
+def _scenes():
+    yield "empty", _header(0), []
+    yield "no_emitter_open", _header(3, depth=2), [FLOOR, _sphere((0, -6, -10), 5), _sphere((9, -8, -6), 3)]
+    yield "sphere_emitter", _header(3), [FLOOR, _sphere((0, 12, -10), 4, light=True), _sphere((0, -6, -10), 5)]
+    yield "plane_flagged_emitter", _header(3), [_plane((0, -12, 0), (0, 1, 0), light=True), CEIL_LIGHT, _sphere((0, -6, -10), 5)]
+    tri = _face([(-10, -11, -18), (10, -11, -18), (0, 8, -14)], (0, 0.2, 1))
+    pent = _face([(12, -10, -8), (18, -6, -8), (16, 2, -8), (9, 3, -8), (7, -5, -8)], (0, 0, 1))
+    yield "triangle_and_pentagon", _header(4), [FLOOR, CEIL_LIGHT, tri, pent]
+    bent = _face([(-14, -10, -12), (-4, -10, -16), (-9, -2, -12), (-4, 6, -16), (-14, 6, -12)], (0, 0, 1))   # not planar, not convex
+    yield "bent_face", _header(4), [FLOOR, CEIL_LIGHT, bent, _sphere((8, -7, -8), 4)]
+    yield "huge_sphere", _header(4), [FLOOR, CEIL_LIGHT, _sphere((0, -80, -20), 70), _sphere((6, -5, -8), 3)]
+    yield "glass_index_one", _header(4, depth=4), [FLOOR, CEIL_LIGHT, _sphere((0, -5, -10), 6, glass=1.0), _sphere((10, -8, -4), 3, glass=1.5)]
+    yield "depth_zero", _header(3, depth=0), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5)]
+    yield "depth_max", _header(3, depth=16, spp=1), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5, glass=1.5)]
+    yield "one_pixel", _header(3, width=1, height=1, spp=5), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5)]
+    yield "odd_frame_no_lens", _header(3, width=37, height=23, spp=3, lens=0.0), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5)]
+    many = [FLOOR, CEIL_LIGHT] + [_sphere((-18 + 1.2 * (i % 31), -10 + 1.2 * (i // 31), -12 - 0.1 * i), 0.5) for i in range(90)]
+    yield "row_of_spheres_overflowing_lists", _header(len(many), width=64, height=36, depth=2, lens=0.0), many
+
+
+SCENES = list(_scenes())
+
+
+
+
+def text_of(header, objs):
+    """The scene stream the reference reads: header object followed by the solids."""
+    return " ".join(json.dumps(o) for o in [header] + objs)

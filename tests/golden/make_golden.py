@@ -14,6 +14,7 @@ Outputs:
   small_room.scene.json / small_mixed.scene.json   synthetic scene streams
   small_room_t8_b1.npz / small_mixed_t8_b0.npz     their full 8-bit images
   rng_kat.json              libstdc++ default_random_engine known answers
+  (golden.json also holds the hashes of the scenes of tests/edge_scenes.py, named "edge:<name>")
 """
 import hashlib
 import json
@@ -88,6 +89,12 @@ def main():
     t2, _ = synth.make("_g2", num_threads=8, num_blurs=0)
     open(os.path.join(HERE, "small_mixed.scene.json"), "w").write(t2)
     out.append(case("small_mixed.scene.json", t2, 8, 0, "small_mixed_t8_b0.npz"))
+
+    # the edge scenes of tests/edge_scenes.py (defined in code: the fixture is the reference's output for them)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import edge_scenes
+    for name, header, objs in edge_scenes.SCENES:
+        out.append(case("edge:" + name, edge_scenes.text_of(header, objs), int(header["num_threads"]), 1))
 
     json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     json.dump(rng_kat(), open(os.path.join(HERE, "rng_kat.json"), "w"), indent=1)

@@ -17,6 +17,15 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def _scene(golden_dir, name):
+    """A golden case's scene: a stream file of tests/golden/, or "edge:<name>" from tests/edge_scenes.py."""
+    if name.startswith("edge:"):
+        import edge_scenes
+        _, header, objs = [s for s in edge_scenes.SCENES if s[0] == name[5:]][0]
+        return S.loads(edge_scenes.text_of(header, objs))
+    return S.read_json_scene(os.path.join(golden_dir, name))
+
+
 def _cases(golden_dir):
     return json.load(open(os.path.join(golden_dir, "golden.json")))
 
@@ -29,7 +38,7 @@ def _ids():
 @pytest.mark.parametrize("i", range(len(_ids())), ids=_ids())
 def test_ref_policy_reproduces_reference_bits(golden_dir, i):
     e = _cases(golden_dir)[i]
-    sc = S.read_json_scene(os.path.join(golden_dir, e["scene"]))
+    sc = _scene(golden_dir, e["scene"])
     sc.header["num_threads"] = e["threads"]
     sc.header["num_blurs"] = e["blurs"]
     o = po.render(sc, policy=po.POLICY_REF, rng_mode=po.RNG_STREAM)
@@ -47,7 +56,7 @@ def test_dev_policy_matches_reference_image(golden_dir, i):
     """Only libm's four transcendental functions differ from the reference: the colours move by ~1e-12
     relative, the 8-bit frame and the ray counters not at all."""
     e = _cases(golden_dir)[i]
-    sc = S.read_json_scene(os.path.join(golden_dir, e["scene"]))
+    sc = _scene(golden_dir, e["scene"])
     sc.header["num_threads"] = e["threads"]
     sc.header["num_blurs"] = e["blurs"]
     o = po.render(sc, policy=po.POLICY_DEV, rng_mode=po.RNG_STREAM)

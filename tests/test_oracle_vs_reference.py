@@ -22,3 +22,22 @@ def test_oracle_equals_reference_binary(cfg, width, threads, blurs, kw):
     assert np.array_equal(ref["rgb"].view(np.uint64), o["rgb"].view(np.uint64))
     img, _ = po.expose(o["rgb"], sc.header["exposure"], blurs)
     assert np.array_equal(img, ref["img"])
+
+
+from edge_scenes import SCENES, text_of          # noqa: E402
+from raytracer_amd import scene as S             # noqa: E402
+
+
+@pytest.mark.parametrize("name,header,objs", SCENES, ids=[s[0] for s in SCENES])
+def test_oracle_equals_reference_binary_on_edge_scenes(name, header, objs):
+    """Empty list, emitters of every kind, triangles, a bent face, glass of index 1, depth 0 and 16, a 1x1 frame ...:
+    the compiled reference and the oracle (reference arithmetic, reference RNG order) agree bit for bit."""
+    text = text_of(header, objs)
+    T = int(header["num_threads"])
+    ref = po.run_reference(text, num_threads=T, num_blurs=1, timeout=120)
+    sc = S.loads(text)
+    o = po.render(sc, policy=po.POLICY_REF, rng_mode=po.RNG_STREAM)
+    assert np.array_equal(ref["rays"], o["rays"])
+    assert np.array_equal(ref["rgb"].view(np.uint64), o["rgb"].view(np.uint64))
+    img, _ = po.expose(o["rgb"], sc.header["exposure"], 1)
+    assert np.array_equal(img, ref["img"])
