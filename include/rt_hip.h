@@ -99,7 +99,7 @@ typedef struct {
     uint64_t plane_tests;
     uint64_t face_tests;
     uint64_t face_vert_tests;
-    uint64_t overflow_rays; /* pipeline: rays whose candidate list overflowed and were tested against every solid */
+    uint64_t overflow_rays; /* pipeline: rays with a long candidate list (more than 6 mask words), tested against every solid by their whole wave */
 } rt_timing;
 
 /* options for rt_set_option */

@@ -520,14 +520,14 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
 }
 
 // narrow phase on one candidate: the reference's double-precision test
-DEV d3 narrow_point(int idx, d3 o, d3 d, const KParams& kp) {
-    const PrimD* pr = kp.prims + idx;
+DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
+    const PrimD* pr = prims + idx;
     const int kind = pr->kind;
     if (kind == RT_KIND_SPHERE) return sphere_point(*pr, o, d);
     if (kind == RT_KIND_PLANE) return plane_point(dmk(pr->a[0], pr->a[1], pr->a[2]), dmk(pr->n[0], pr->n[1], pr->n[2]), o, d);
-    return face_point(*pr, kp.verts, o, d);
+    return face_point(*pr, verts, o, d);
 }
-DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) { consider(narrow_point(idx, o, d, kp), idx, o, h); }
+DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) { consider(narrow_point(idx, o, d, kp.prims, kp.verts), idx, o, h); }
 
 // exact test of every "always" solid, read from `tab` (LDS or global) at wave-uniform addresses
 constexpr int ALW_HEAD = 12;
@@ -571,6 +571,66 @@ enum { ST_NEED = 0, ST_ALIVE = 1, ST_DEAD = 2 };
 // ---- single-kernel renderer: persistent lanes, broad + narrow + shading in one loop ------------
 // Used for the reference-order validation mode (one lane per reference thread) and selectable for
 // the per-pixel mode (RT_MODE=mega); the per-pixel default is the three-kernel pipeline below.
+// Closest hit of one ray per lane against the whole list (get_intersection, main.cpp:34-43) inside a persistent
+// kernel: FP32 broad phase over the LDS windows, exact narrow phase on what it keeps, always-tested solids from global
+// memory.  Called by every thread of the workgroup; a list of more than one window is staged window by window in
+// lock-step (`lockstep`), a single window was staged once by the caller.
+template <int BLOCK>
+DEV void stage_window(const KParams& kp, float4* lds, int c) {
+    const ChunkDesc ch = kp.chunks[c];
+    const float4* src = kp.records + ch.gofs;
+    for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
+}
+
+template <int BLOCK>
+DEV Hit closest_hit_block(const KParams& kp, float4* lds, bool lockstep, bool alive, d3 o, d3 d, unsigned& ncand_total) {
+    Hit h;
+    h.q = __builtin_inf(); h.idx = -1;
+    h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+    int cand[CAND_CAP];
+    int ncand = 0;
+    auto narrow = [&]() {
+        for (int k = 0; k < ncand; k++) if (cand[k] < kp.n_prims) narrow_one(cand[k], o, d, kp, h);
+        ncand_total += (unsigned)ncand;
+        ncand = 0;
+    };
+    RayRec rr;
+    if (alive) rr = broad_setup(o, d, kp.T, kp.cmax);
+    for (int c = 0; c < kp.nchunks; c++) {
+        if (lockstep) {
+            if (c > 0) __syncthreads();
+            stage_window<BLOCK>(kp, lds, c);
+            __syncthreads();
+        }
+        if (alive) {
+            const ChunkDesc ch = kp.chunks[c];
+            for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
+                const float4 r0 = lds[i], r1 = lds[i + 1], r2 = lds[i + 2], r3 = lds[i + 3];
+                float hb0, hb1, hb2, hb3, q0, q1, q2, q3;
+                const float s0 = broad_s(r0, rr.a, rr.b, hb0, q0);
+                const float s1 = broad_s(r1, rr.a, rr.b, hb1, q1);
+                const float s2 = broad_s(r2, rr.a, rr.b, hb2, q2);
+                const float s3 = broad_s(r3, rr.a, rr.b, hb3, q3);
+                const float thr = rr.b.w;
+                if ((s0 >= thr) | (s1 >= thr) | (s2 >= thr) | (s3 >= thr)) {
+                    const int base = ch.first_index + i;
+                    if (s0 >= thr && !broad_behind(hb0, q0, rr.c)) cand[ncand++] = base;
+                    if (s1 >= thr && !broad_behind(hb1, q1, rr.c)) cand[ncand++] = base + 1;
+                    if (s2 >= thr && !broad_behind(hb2, q2, rr.c)) cand[ncand++] = base + 2;
+                    if (s3 >= thr && !broad_behind(hb3, q3, rr.c)) cand[ncand++] = base + 3;
+                    if (ncand > CAND_CAP - BROAD_UNROLL) narrow();
+                }
+            }
+        }
+    }
+    if (alive) {
+        narrow_always(kp.always, kp.n_always, o, d, h);
+        ncand_total += (unsigned)kp.n_always;
+        narrow();
+    }
+    return h;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
     extern __shared__ float4 lds[];
@@ -588,16 +648,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
     unsigned long long item_rays = 0;
     double fst_mem[RT_MAXV * 3];
     FactorStack fst; fst.base = fst_mem; fst.stride = 1;
-    int cand[CAND_CAP];
-
-    auto stage = [&](int c) {
-        const ChunkDesc ch = kp.chunks[c];
-        const float4* src = kp.records + ch.gofs;
-        for (int i = threadIdx.x; i < ch.count; i += BLOCK) lds[i] = src[i];
-    };
 
     if (!lockstep) {
-        stage(0);
+        stage_window<BLOCK>(kp, lds, 0);
         __syncthreads();
     }
 
@@ -643,51 +696,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
             }
         }
 
-        // ---- closest hit (get_intersection, main.cpp:34-43)
-        Hit h;
-        h.q = __builtin_inf(); h.idx = -1;
-        h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-        int ncand = 0;
-        auto narrow = [&]() {
-            for (int k = 0; k < ncand; k++) if (cand[k] < kp.n_prims) narrow_one(cand[k], s.o, s.d, kp, h);
-            ncand_total += (unsigned)ncand;
-            ncand = 0;
-        };
-
-        RayRec rr;
-        if (alive) rr = broad_setup(s.o, s.d, kp.T, kp.cmax);
-        for (int c = 0; c < kp.nchunks; c++) {
-            if (lockstep) {
-                if (c > 0) __syncthreads();
-                stage(c);
-                __syncthreads();
-            }
-            if (alive) {
-                const ChunkDesc ch = kp.chunks[c];
-                for (int i = 0; i < ch.count; i += BROAD_UNROLL) {
-                    const float4 r0 = lds[i], r1 = lds[i + 1], r2 = lds[i + 2], r3 = lds[i + 3];
-                    float hb0, hb1, hb2, hb3, q0, q1, q2, q3;
-                    const float s0 = broad_s(r0, rr.a, rr.b, hb0, q0);
-                    const float s1 = broad_s(r1, rr.a, rr.b, hb1, q1);
-                    const float s2 = broad_s(r2, rr.a, rr.b, hb2, q2);
-                    const float s3 = broad_s(r3, rr.a, rr.b, hb3, q3);
-                    const float thr = rr.b.w;
-                    if ((s0 >= thr) | (s1 >= thr) | (s2 >= thr) | (s3 >= thr)) {
-                        const int base = ch.first_index + i;
-                        if (s0 >= thr && !broad_behind(hb0, q0, rr.c)) cand[ncand++] = base;
-                        if (s1 >= thr && !broad_behind(hb1, q1, rr.c)) cand[ncand++] = base + 1;
-                        if (s2 >= thr && !broad_behind(hb2, q2, rr.c)) cand[ncand++] = base + 2;
-                        if (s3 >= thr && !broad_behind(hb3, q3, rr.c)) cand[ncand++] = base + 3;
-                        if (ncand > CAND_CAP - BROAD_UNROLL) narrow();
-                    }
-                }
-            }
-        }
-
+        const Hit h = closest_hit_block<BLOCK>(kp, lds, lockstep, alive, s.o, s.d, ncand_total);
         if (alive) {
-            narrow_always(kp.always, kp.n_always, s.o, s.d, h);
-            ncand_total += (unsigned)kp.n_always;
-            narrow();
             nrays++;
             item_rays++;
             if (!segment(s, h, fst, item, item_rays, kp)) state = ST_NEED;
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 #define SHADE_BLOCK 512
 #endif
 #ifndef SHADE_WAVES
-#define SHADE_WAVES 4
+#define SHADE_WAVES 8
 #endif
 constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS windows are multiples of it
 constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
@@ -886,32 +896,66 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
 
 // closest hit of the ray queued at `pos`: the always-tested solids (table `alw`, LDS) and the ray's kept records
 // through the reference's exact test
-DEV Hit find_hit(const WfParams& w, unsigned pos, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
+// Closest hit of the ray queued at `pos` (get_intersection, main.cpp:34-43): the always-tested solids (table `alw`, LDS)
+// and the ray's kept records through the reference's exact test.  Called by whole waves.
+//
+// A ray that keeps very many records (a NaN ray keeps every record, a ray with a distant origin has wide error bounds;
+// list overflow is the extreme case) would hold one lane busy with hundreds of exact tests while its wave, its workgroup
+// (barrier) and in the end the kernel wait: 1000 tests are 0.25 ms, more than a whole round of a small frame.  Such a
+// ray is tested against EVERY solid by its whole wave instead -- lane l takes solids l, l+64, ... -- and the 64 partial
+// results are merged with get_intersection's order-independent acceptance (consider_q).
+constexpr unsigned HEAVY_WORDS = 6, HEAVY_BITS = 48;   // shared out: lists of more than 6 mask words with more than 48 records
+
+DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
+    const int lane = threadIdx.x & 63;
     Hit h;
     h.q = __builtin_inf(); h.idx = -1;
     h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-    const unsigned n = w.cand_cnt[pos];
-    if (n == WF_OVERFLOW) {
-        // more non-zero words than list entries: exact test against the whole list
-        for (int i = 0; i < w.kp.n_prims; i++) narrow_one(i, o, d, w.kp, h);
-        ncand_total += (unsigned)w.kp.n_prims;
-        atomicAdd(&w.kp.ctrl[6], 1u);
-        return h;
-    }
-    narrow_always(alw, w.kp.n_always, o, d, h);
-    ncand_total += (unsigned)w.kp.n_always;
+    const unsigned n = live ? w.cand_cnt[pos] : 0u;
     const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
-    for (unsigned e = 0; e < n; e++) {
-        const uint2 ent = cl[e];
-        unsigned m = ent.y;
-        ncand_total += (unsigned)__popc(m);
-        while (m) {
-            const int k = __clz((int)m);
-            m &= ~(0x80000000u >> k);
-            const int idx = (int)ent.x * BROAD_GROUP + k;
-            // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
-            // included: indices past the list are never dereferenced
-            if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+    bool heavy = (n == WF_OVERFLOW);
+    if (!heavy && n > HEAVY_WORDS) {
+        unsigned c = 0;
+        for (unsigned e = 0; e < n; e++) c += (unsigned)__popc(cl[e].y);
+        heavy = c > HEAVY_BITS;
+    }
+    if (live && !heavy) {
+        narrow_always(alw, w.kp.n_always, o, d, h);
+        ncand_total += (unsigned)w.kp.n_always;
+        for (unsigned e = 0; e < n; e++) {
+            const uint2 ent = cl[e];
+            unsigned m = ent.y;
+            ncand_total += (unsigned)__popc(m);
+            while (m) {
+                const int k = __clz((int)m);
+                m &= ~(0x80000000u >> k);
+                const int idx = (int)ent.x * BROAD_GROUP + k;
+                // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
+                // included: indices past the list are never dereferenced
+                if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+            }
+        }
+    }
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {
+        const int src = __builtin_ctzll(hm);
+        hm &= hm - 1ull;
+        const d3 ob = dmk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+        const d3 db = dmk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+        Hit hl;
+        hl.q = __builtin_inf(); hl.idx = -1;
+        hl.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+        for (int i = lane; i < w.kp.n_prims; i += 64) narrow_one(i, ob, db, w.kp, hl);
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(hl.q, off, 64);
+            const int oi = __shfl_xor(hl.idx, off, 64);
+            const d3 op = dmk(__shfl_xor(hl.p.x, off, 64), __shfl_xor(hl.p.y, off, 64), __shfl_xor(hl.p.z, off, 64));
+            if (oi >= 0) consider_q(oq, op, oi, hl);
+        }
+        if (lane == src) {
+            h = hl;
+            ncand_total += (unsigned)w.kp.n_prims;
+            atomicAdd(&w.kp.ctrl[6], 1u);
         }
     }
     return h;
@@ -942,15 +986,24 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     const unsigned trips = (count + stride - 1) / stride;
     for (unsigned t = 0; t < trips; t++) {
         const unsigned pos = t * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = pos < count;
         bool alive = false;
         PathState s;
         unsigned slot = 0;
         SHADE_TICK(0);
-        if (pos < count) {
+        // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
+        d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
+        if (live) {
+            const double* sd = w.sd[qi] + pos;
+            const size_t n = w.slots;
+            ro = dmk(sd[(SD_O + 0) * n], sd[(SD_O + 1) * n], sd[(SD_O + 2) * n]);
+            rd = dmk(sd[(SD_D + 0) * n], sd[(SD_D + 1) * n], sd[(SD_D + 2) * n]);
+        }
+        const Hit h = find_hit(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
+        SHADE_TICK(1);
+        if (live) {
             slot = w.queue[qi][pos];
             load_state(w, qi, pos, slot, s);
-            const Hit h = find_hit(w, pos, s.o, s.d, alw, ncand_total);
-            SHADE_TICK(1);
             nrays++;
             FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Kernel trace of tools/probe_once.py (rank 0 of an N-rank partition), last frame launch by launch
+#   gpurun -- tools/trace_probe.sh tag N [workload]
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 180 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o vm -- python $root/tools/probe_once.py "$@" > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+python - $out/trace/vm_kernel_trace.csv <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'init_kernel' in r['Kernel_Name']]
+i0 = idx[-1]
+t0 = int(rows[i0]['Start_Timestamp'])
+for r in rows[i0:]:
+    st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:28]
+    print(f"{name:28s} start {(st - t0) / 1e3:9.1f} us  dur {(en - st) / 1e3:8.1f} us")
+PY
