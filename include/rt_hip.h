@@ -112,8 +112,11 @@ enum {
     RT_OPT_CHUNK_RECORDS = 5,  /* LDS window in 16-byte records (next rt_upload_scene)          */
     RT_OPT_MAX_SLOTS = 6,      /* pixels whose path state is kept at once (memory cap)          */
     RT_OPT_FUSE_NARROW = 7,    /* retired (the narrow phase always runs inside shade_kernel); accepted, ignored */
-    RT_OPT_OVERLAP = 8         /* 1..3 sub-pipelines, each with an equal share of the pixels and a stream of its  */
+    RT_OPT_OVERLAP = 8,        /* 1..3 sub-pipelines, each with an equal share of the pixels and a stream of its  */
                                /* own, so that one's kernels fill the tails of the other's (default 2)            */
+    RT_OPT_ACCEL = 9           /* 0 (default): every ray is tested against every solid, the work get_intersection  */
+                               /* defines (main.cpp:34-43); 1: candidate solids come from a front-to-back walk of  */
+                               /* a uniform grid instead -- same closest hit, same output bits, far fewer tests    */
 };
 enum { RT_MODE_PIPELINE = 0, RT_MODE_SINGLE_KERNEL = 1 };
 

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB", os.path.join(HERE, "librt_hip.so"))   # 
 
 RT_OK = 0
 # rt_set_option keys / values (include/rt_hip.h)
-OPT_MODE, OPT_TIMING_DETAIL, OPT_BLOCK, OPT_BROAD_BLOCK, OPT_WG_PER_CU, OPT_CHUNK_RECORDS, OPT_MAX_SLOTS, OPT_FUSE_NARROW, OPT_OVERLAP = range(9)
+OPT_MODE, OPT_TIMING_DETAIL, OPT_BLOCK, OPT_BROAD_BLOCK, OPT_WG_PER_CU, OPT_CHUNK_RECORDS, OPT_MAX_SLOTS, OPT_FUSE_NARROW, OPT_OVERLAP, OPT_ACCEL = range(10)
 MODE_PIPELINE, MODE_SINGLE_KERNEL = 0, 1
 STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE", -4: "RT_ERR_SCENE",
           -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}

@@ -724,6 +724,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 #ifndef SHADE_PROFILE
 #define SHADE_PROFILE 0
 #endif
+#ifndef WALK_DEBUG
+#define WALK_DEBUG 0
+#endif
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
@@ -894,8 +897,175 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
     }
 }
 
-// closest hit of the ray queued at `pos`: the always-tested solids (table `alw`, LDS) and the ray's kept records
-// through the reference's exact test
+// ---- grid walk: the broad phase with a uniform grid over the bounded solids (option RT_OPT_ACCEL) ----------------
+// get_intersection (main.cpp:34-43) tests every solid for every ray; broad_kernel does the same with a cheap test.
+// walk_kernel produces candidate lists that lead to the same closest hit from far fewer tests: every lane walks its
+// own ray through a uniform grid (3D-DDA, front to back), applies broad_kernel's conservative test to the solids
+// listed in the cells it visits, and stops once it has left behind a sphere that the exact test is CERTAIN to accept.
+// Nothing here decides a result: the exact phase still picks the closest hit among the candidates with the
+// reference's own arithmetic.  What has to hold is that no candidate list lacks the solid the full scan would have
+// selected:
+//   * a solid is listed in every cell that its bounding box, grown by `pad`, overlaps; float rounding moves the
+//     walk's cell boundaries by far less than `pad` (boundaries are recomputed from the integer cell index at every
+//     step, never accumulated; rays that start further away than `far` from the grid are handed to the exact
+//     full scan instead), so a point of the exact ray at parameter t lies within `pad` of the cell the walk is in
+//     at t, and a solid hit there is listed in that cell;
+//   * a hit is certain when the float discriminant, evaluated relative to the sphere's centre, exceeds a bound M on
+//     its own error and a root exceeds the reference's 0.001 threshold by more than the bound Mt on the root's
+//     error; then the exact test returns a valid point no further than tU = root + Mt.  The walk ends when the
+//     current cell's exit parameter exceeds the smallest tU by more than `pad`: every solid not yet seen is hit,
+//     if at all, strictly further away than the certain hit, and cannot be the closest one (nor tie with it).
+// Rays with a non-finite component keep every record in broad_kernel; here they are marked as overflowed lists, for
+// which the exact phase scans every solid.
+struct GridD {
+    float lo[3], hi[3];            // box of the grid, relative to the translation T
+    float cell[3], inv_cell[3];    // cell size and its reciprocal
+    int n[3];                      // cells per axis
+    float pad;                     // growth of the solids' boxes at insertion; slack of the early exit
+    float far;                     // largest |origin component| (relative to T) the walk accepts
+    const uint4* cells;            // per cell two uint4 (32 bytes, one cache line half): the broad-phase record
+                                   // (c, R^2 - |c|^2) of the cell's FIRST item as float bits, then (file index of that
+                                   // item's solid, float bits of a lower bound of r^2 if it is a sphere else of -1,
+                                   // items in the cell, place of the cell's further items in item_rec / item_aux).
+                                   // Most cells list at most one solid: one load per step, whose address depends on
+                                   // the walk's arithmetic only, so it is issued a step ahead.
+    const float4* item_rec;        // further items: record
+    const uint2* item_aux;         //                (file index, r^2 bound bits)
+};
+
+DEV float grid_bound(const GridD& g, int k, int i) { return __builtin_fmaf((float)i, g.cell[k], g.lo[k]); }
+
+__global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD g) {
+    const unsigned count = w.counts[w.iter];
+    const unsigned stride = gridDim.x * blockDim.x;
+    const float inf = __builtin_inff();
+    for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
+        const float4 ra = w.rec[0][pos], rb = w.rec[1][pos];
+        uint2* out = w.cand + (size_t)pos * WF_CAND_CAP;
+        const float o[3] = {0.5f * rb.x, 0.5f * rb.y, 0.5f * rb.z};
+        const float d[3] = {-ra.x * (1.0f / BROAD_SCALE), -ra.y * (1.0f / BROAD_SCALE), -ra.z * (1.0f / BROAD_SCALE)};
+        const float thr = rb.w;
+        // finite test by arithmetic: x - x is 0 for finite x, NaN otherwise
+        const float chk = (o[0] - o[0]) + (o[1] - o[1]) + (o[2] - o[2]) + (d[0] - d[0]) + (d[1] - d[1]) + (d[2] - d[2]) + (thr - thr) + (ra.w - ra.w);
+        const float omax = __builtin_fmaxf(__builtin_fabsf(o[0]), __builtin_fmaxf(__builtin_fabsf(o[1]), __builtin_fabsf(o[2])));
+        if (!(chk == 0.0f) || !(omax <= g.far)) {
+#if WALK_DEBUG
+            atomicAdd(&w.kp.ctrl[!(chk == 0.0f) ? 8 : 9], 1u);
+#endif
+            w.cand_cnt[pos] = WF_OVERFLOW; continue;
+        }
+
+        // ---- the ray's interval inside the grid box, and the walk's state
+        float t0 = 0.0f, t1 = inf;
+        bool miss = false;
+        float inv[3];
+        int step[3], cell[3];
+        for (int k = 0; k < 3; k++) {
+            if (__builtin_fabsf(d[k]) < 1e-30f) {
+                step[k] = 0; inv[k] = 0.0f;
+                if (o[k] < g.lo[k] || o[k] > g.hi[k]) miss = true;
+            } else {
+                inv[k] = 1.0f / d[k];
+                step[k] = d[k] > 0.0f ? 1 : -1;
+                const float ta = (g.lo[k] - o[k]) * inv[k], tb = (g.hi[k] - o[k]) * inv[k];
+                t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+                t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+            }
+        }
+        // the box is larger than every listed solid by 2 pad: a ray that the float interval test puts outside it by
+        // more than its own rounding cannot hit any of them
+        if (miss || t0 > t1 * 1.0001f + 4.0f * g.pad) { w.cand_cnt[pos] = 0u; continue; }
+        float tmax[3];
+        for (int k = 0; k < 3; k++) {
+            const float p = __builtin_fmaf(d[k], t0, o[k]);
+            int c = (int)__builtin_floorf((p - g.lo[k]) * g.inv_cell[k]);
+            c = c < 0 ? 0 : (c >= g.n[k] ? g.n[k] - 1 : c);
+            cell[k] = c;
+            tmax[k] = step[k] == 0 ? inf : (grid_bound(g, k, c + (step[k] > 0 ? 1 : 0)) - o[k]) * inv[k];
+        }
+
+        // error scale of this ray's float tests: |o| + largest |c| + R (as in broad_setup)
+        const float S = __builtin_sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) * 1.0001f + w.kp.cmax;
+        float tU = inf;
+        unsigned n = 0, cur_j = 0xffffffffu, cur_m = 0u;
+
+        // one listed solid: broad_kernel's test, then (spheres) the certain-hit test
+        auto test_item = [&](const float4 rec, unsigned idx, float r2) {
+            const float s = broad_s2(rec, ra, rb);
+            if (s <= thr) return;                               // kept iff s > thr
+            const unsigned j = idx / (unsigned)BROAD_GROUP, bit = 0x80000000u >> (idx % (unsigned)BROAD_GROUP);
+            if (j == cur_j) cur_m |= bit;
+            else {
+                if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) out[n++] = make_uint2(cur_j, cur_m); else n = WF_OVERFLOW; }
+                cur_j = j; cur_m = bit;
+            }
+            if (r2 >= 0.0f) {
+                const float ox = o[0] - rec.x, oy = o[1] - rec.y, oz = o[2] - rec.z;
+                const float hb = __builtin_fmaf(d[2], oz, __builtin_fmaf(d[1], oy, d[0] * ox));
+                const float oc2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+                const float disc = __builtin_fmaf(hb, hb, r2 - oc2);
+                // bound of the float discriminant's error, about 3x the term-by-term count: rounding of o and c to
+                // float and of their difference (S |oc|), of the products and sums (oc2), of d (hb^2 + oc2)
+                const float M = (48.0f * F32_U) * __builtin_fmaf(S, __builtin_sqrtf(oc2), oc2) + (16.0f * F32_U) * __builtin_fmaf(hb, hb, oc2) + 1e-12f;
+                if (disc > M) {
+                    const float sq = __builtin_sqrtf(disc);
+                    const float Mt = 2.0f * __builtin_sqrtf(M) + (8.0f * F32_U) * (__builtin_fabsf(hb) + sq + S) + 1e-6f;
+                    const float ta = -hb - sq, tb = sq - hb;
+                    const float lim = (float)RT_EPS + Mt;
+                    const float th = ta > lim ? ta : (tb > lim ? tb : inf);
+                    tU = __builtin_fminf(tU, th + Mt);
+                }
+            }
+        };
+
+        const int max_steps = g.n[0] + g.n[1] + g.n[2] + 4;
+        unsigned ci = (unsigned)((cell[2] * g.n[1] + cell[1]) * g.n[0] + cell[0]);
+        uint4 c0 = g.cells[2 * (size_t)ci], c1 = g.cells[2 * (size_t)ci + 1];
+#if WALK_DEBUG
+        int nsteps = 0; unsigned ntests = 0;
+#endif
+        for (int it = 0; it < max_steps; it++) {
+            // the next cell: through the nearest of the three next boundaries; its record is requested before the
+            // current cell's solids are tested
+            const int ax = (tmax[0] <= tmax[1] && tmax[0] <= tmax[2]) ? 0 : (tmax[1] <= tmax[2] ? 1 : 2);
+            const float texit = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
+            const int st = ax == 0 ? step[0] : (ax == 1 ? step[1] : step[2]);
+            const int c = (ax == 0 ? cell[0] : (ax == 1 ? cell[1] : cell[2])) + st;
+            const int nn = ax == 0 ? g.n[0] : (ax == 1 ? g.n[1] : g.n[2]);
+            const bool has_next = st != 0 && (unsigned)c < (unsigned)nn;   // st == 0: a point ray (every tmax infinite)
+            uint4 n0 = c0, n1 = c1;
+            if (has_next) {
+                const float oo = ax == 0 ? o[0] : (ax == 1 ? o[1] : o[2]);
+                const float iv = ax == 0 ? inv[0] : (ax == 1 ? inv[1] : inv[2]);
+                const float tn = (grid_bound(g, ax, c + (st > 0 ? 1 : 0)) - oo) * iv;
+                if (ax == 0) { cell[0] = c; tmax[0] = tn; } else if (ax == 1) { cell[1] = c; tmax[1] = tn; } else { cell[2] = c; tmax[2] = tn; }
+                ci = (unsigned)((cell[2] * g.n[1] + cell[1]) * g.n[0] + cell[0]);
+                n0 = g.cells[2 * (size_t)ci]; n1 = g.cells[2 * (size_t)ci + 1];
+            }
+            const unsigned cnt = c1.z;
+#if WALK_DEBUG
+            nsteps++; ntests += cnt;
+#endif
+            if (cnt != 0u) {
+                test_item(make_float4(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w)), c1.x, __uint_as_float(c1.y));
+                for (unsigned i = 0; i + 1u < cnt; i++) {
+                    const uint2 aux = g.item_aux[c1.w + i];
+                    test_item(g.item_rec[c1.w + i], aux.x, __uint_as_float(aux.y));
+                }
+            }
+            if (!has_next || texit - g.pad > tU) break;
+            c0 = n0; c1 = n1;
+        }
+        if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) out[n++] = make_uint2(cur_j, cur_m); else n = WF_OVERFLOW; }
+#if WALK_DEBUG
+        if (n == WF_OVERFLOW) atomicAdd(&w.kp.ctrl[10], 1u);
+        atomicAdd(&w.kp.ctrl[11], (unsigned)nsteps);
+        atomicAdd(&w.kp.ctrl[12], ntests);
+#endif
+        w.cand_cnt[pos] = n;
+    }
+}
+
 // Closest hit of the ray queued at `pos` (get_intersection, main.cpp:34-43): the always-tested solids (table `alw`, LDS)
 // and the ray's kept records through the reference's exact test.  Called by whole waves.
 //
@@ -1171,6 +1341,9 @@ struct rt_context {
     void* d_verts = nullptr;
     void* d_mats = nullptr;
     void* d_always = nullptr; int n_always = 0, always_doubles = 0;
+    // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
+    uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
+    GridD grid{}; bool grid_ok = false; size_t grid_items = 0;
     int nchunks = 0;
     int max_chunk_records = 0;
     int n_records_padded = 0;  // records incl. the NaN padding of every LDS window
@@ -1210,6 +1383,8 @@ struct rt_context {
     int chunk_records = 8192;  // LDS window in records (16 bytes each)
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
+    double grid_density = 2.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY)
 };
 
 namespace {
@@ -1227,6 +1402,8 @@ int fail(rt_context* h, int code, const std::string& msg) {
 
 void free_scene(rt_context* h) {
     hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
+    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux);
+    h->d_cells = nullptr; h->d_item_rec = nullptr; h->d_item_aux = nullptr; h->grid_ok = false;
     h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = h->d_always = nullptr;
     h->have_scene = false;
 }
@@ -1258,6 +1435,134 @@ double make_record(const double* c, double R, float* out) {
     const double Rr = R * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
     out[3] = round_up_f(Rr * Rr - c2);
     return sqrt(cn) + Rr;
+}
+
+
+// Uniform grid over the bounded solids that are not in the always table, for walk_kernel.  bc/br: bounding sphere of
+// every solid (radius < 0: unbounded), T: the translation of the float coordinates.  A solid is listed in every cell
+// that the box of its bounding sphere, grown by `pad`, overlaps.  Returns false when the scene cannot use the grid
+// (an unbounded solid outside the always table would have to be listed everywhere).
+struct GridHost {
+    GridD g;
+    size_t items = 0;                 // (solid, cell) pairs listed
+    std::vector<unsigned> cells;      // 8 per cell (GridD::cells)
+    std::vector<float> item_rec;      // 4 per further item
+    std::vector<unsigned> item_aux;   // 2 per further item
+};
+
+bool build_grid(int n_prims, const std::vector<PrimD>& pd, const std::vector<double>& bc, const std::vector<double>& br,
+                const std::vector<char>& always, const double* T, double density, GridHost& out) {
+    const double U = 5.9604645e-8;
+    std::vector<int> ids;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n_prims; i++) {
+        if (always[i]) continue;
+        if (br[i] < 0) return false;
+        ids.push_back(i);
+        for (int k = 0; k < 3; k++) {
+            const double c = bc[(size_t)i * 3 + k] - T[k];
+            if (c - br[i] < lo[k]) lo[k] = c - br[i];
+            if (c + br[i] > hi[k]) hi[k] = c + br[i];
+        }
+    }
+    GridD& g = out.g;
+    memset(&g, 0, sizeof(g));
+    if (ids.empty()) {                     // one empty cell: every walk ends at once with an empty list
+        for (int k = 0; k < 3; k++) { g.lo[k] = -1.0f; g.hi[k] = 1.0f; g.cell[k] = 2.0f; g.inv_cell[k] = 0.5f; g.n[k] = 1; }
+        g.pad = 1e-3f; g.far = 1e30f;
+        out.cells.assign(8, 0u);
+        out.item_rec.assign(4, 0.0f); out.item_aux.assign(2, 0u);
+        return true;
+    }
+    double reach = 0;
+    for (int k = 0; k < 3; k++) { reach = fmax(reach, fabs(lo[k])); reach = fmax(reach, fabs(hi[k])); }
+    if (!(reach < 1e15)) return false;
+    if (reach < 1e-6) reach = 1e-6;
+    // resolution: about `density` cells per listed solid, cells as cubic as the box allows
+    double ext[3], vol = 1, emax = 0;
+    for (int k = 0; k < 3; k++) { ext[k] = hi[k] - lo[k]; emax = fmax(emax, ext[k]); }
+    for (int k = 0; k < 3; k++) { if (ext[k] < 1e-3 * emax) { const double grow = 0.5 * (1e-3 * emax - ext[k]); lo[k] -= grow; hi[k] += grow; ext[k] = hi[k] - lo[k]; } vol *= ext[k]; }
+    const double per_len = cbrt(density * (double)ids.size() / vol);
+    size_t cells = 1;
+    double cell_min = 1e300;
+    for (int k = 0; k < 3; k++) {
+        int n = (int)ceil(ext[k] * per_len);
+        n = n < 1 ? 1 : (n > 256 ? 256 : n);
+        g.n[k] = n;
+        cells *= (size_t)n;
+        cell_min = fmin(cell_min, ext[k] / n);
+    }
+    // pad: what float rounding can move a cell boundary or a point of the ray, 128 u (|origin| + reach) with a wide
+    // margin (the walk's own count is about 11 u).  Origins up to `far` from T are walked; `far` is as large as a
+    // pad of 2 % of the smallest cell allows, at least 8 and at most 1024 times the grid's reach.
+    double far = 0.02 * cell_min / (128.0 * U) - reach;
+    far = fmin(fmax(far, 8.0 * reach), 1024.0 * reach);
+    const double pad = 128.0 * U * (far + reach);
+    for (int k = 0; k < 3; k++) { lo[k] -= 2.0 * pad; hi[k] += 2.0 * pad; }
+    // the device recomputes a boundary as fma((float)i, cell, lo): lists are built from the same float values, and the
+    // upper corner is the boundary of index n
+    for (int k = 0; k < 3; k++) {
+        g.lo[k] = (float)lo[k];
+        if ((double)g.lo[k] > lo[k]) g.lo[k] = nextafterf(g.lo[k], -INFINITY);
+        g.cell[k] = round_up_f((hi[k] - (double)g.lo[k]) / g.n[k]);
+        g.inv_cell[k] = 1.0f / g.cell[k];
+        g.hi[k] = fmaf((float)g.n[k], g.cell[k], g.lo[k]);
+    }
+    g.pad = round_up_f(pad); g.far = (float)far;
+    auto cell_range = [&](int k, double a, double b, int& c0, int& c1) {
+        c0 = (int)floor((a - (double)g.lo[k]) / (double)g.cell[k]);
+        c1 = (int)floor((b - (double)g.lo[k]) / (double)g.cell[k]);
+        if (c0 < 0) c0 = 0;
+        if (c1 >= g.n[k]) c1 = g.n[k] - 1;
+        if (c1 < c0) c1 = c0;
+    };
+    std::vector<unsigned> cnt(cells, 0u), more(cells, 0u);
+    out.cells.assign(cells * 8, 0u);
+    for (int pass = 0; pass < 2; pass++) {
+        for (size_t q = 0; q < ids.size(); q++) {
+            const int i = ids[q];
+            int a0[3], a1[3];
+            double cc[3];
+            for (int k = 0; k < 3; k++) {
+                cc[k] = bc[(size_t)i * 3 + k] - T[k];
+                cell_range(k, cc[k] - br[i] - pad, cc[k] + br[i] + pad, a0[k], a1[k]);
+            }
+            float r4[4] = {0, 0, 0, 0};
+            float r2 = -1.0f;
+            if (pass == 1) {
+                make_record(cc, br[i], r4);
+                if (pd[i].kind == RT_KIND_SPHERE) {      // lower bound of r^2 for the certain-hit test
+                    const double v = pd[i].radius * pd[i].radius * (1.0 - 1e-6);
+                    r2 = (float)v;
+                    if ((double)r2 > v) r2 = nextafterf(r2, -INFINITY);
+                    if (!(r2 >= 0.0f)) r2 = 0.0f;
+                }
+            }
+            for (int z = a0[2]; z <= a1[2]; z++) for (int y = a0[1]; y <= a1[1]; y++) for (int x = a0[0]; x <= a1[0]; x++) {
+                const size_t ci = ((size_t)z * g.n[1] + y) * g.n[0] + x;
+                if (pass == 0) { cnt[ci]++; continue; }
+                unsigned* cr = &out.cells[ci * 8];
+                const unsigned k = cr[6]++;
+                if (k == 0) {
+                    memcpy(cr, r4, 16);
+                    cr[4] = (unsigned)i; memcpy(&cr[5], &r2, 4); cr[7] = more[ci];
+                } else {
+                    const size_t at = (size_t)more[ci] + k - 1;
+                    memcpy(&out.item_rec[at * 4], r4, 16);
+                    out.item_aux[at * 2] = (unsigned)i; memcpy(&out.item_aux[at * 2 + 1], &r2, 4);
+                }
+            }
+        }
+        if (pass == 0) {
+            size_t extra = 0, total = 0;
+            for (size_t c = 0; c < cells; c++) { more[c] = (unsigned)extra; if (cnt[c] > 1) extra += cnt[c] - 1; total += cnt[c]; }
+            if (total > (1u << 28)) return false;
+            out.items = total;
+            out.item_rec.assign(extra * 4 + 4, 0.0f);
+            out.item_aux.assign(extra * 2 + 2, 0u);
+        }
+    }
+    return true;
 }
 
 void fill_kparams(rt_context* h, KParams& kp) {
@@ -1348,6 +1653,8 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_WG_PER_CU")) rt_set_option(h, RT_OPT_WG_PER_CU, atoi(e));
     if (const char* e = getenv("RT_CHUNK_RECORDS")) rt_set_option(h, RT_OPT_CHUNK_RECORDS, atoi(e));
     if (const char* e = getenv("RT_OVERLAP")) rt_set_option(h, RT_OPT_OVERLAP, atoi(e));
+    if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
+    if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
     return RT_OK;
 }
@@ -1376,6 +1683,9 @@ int rt_set_option(rt_handle h, int key, int value) {
         case RT_OPT_OVERLAP:
             if (value < 1 || value > RT_MAX_SUB) return fail(h, RT_ERR_ARG, "rt_set_option: overlap must be 1..3");
             h->overlap = value; return RT_OK;
+        case RT_OPT_ACCEL:
+            if (value != 0 && value != 1) return fail(h, RT_ERR_ARG, "rt_set_option: accel must be 0 or 1");
+            h->accel = value; return RT_OK;
         default: return fail(h, RT_ERR_ARG, "rt_set_option: unknown key");
     }
 }
@@ -1635,7 +1945,22 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     const int always_doubles = (int)alw.size();
     if (alw.empty()) alw.push_back(0.0);
 
+    GridHost gh;
+    const bool grid_ok = build_grid(n_prims, pd, bc, br, always, T, h->grid_density, gh);
+
     free_scene(h);
+    if (grid_ok) {
+        HIP_TRY(h, hipMalloc((void**)&h->d_cells, gh.cells.size() * sizeof(unsigned)));
+        HIP_TRY(h, hipMalloc((void**)&h->d_item_rec, gh.item_rec.size() * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->d_item_aux, gh.item_aux.size() * sizeof(unsigned)));
+        HIP_TRY(h, hipMemcpy(h->d_cells, gh.cells.data(), gh.cells.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_item_rec, gh.item_rec.data(), gh.item_rec.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_item_aux, gh.item_aux.data(), gh.item_aux.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        h->grid = gh.g;
+        h->grid.cells = h->d_cells; h->grid.item_rec = h->d_item_rec; h->grid.item_aux = h->d_item_aux;
+        h->grid_items = gh.items;
+        h->grid_ok = true;
+    }
     HIP_TRY(h, hipMalloc(&h->d_always, alw.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_always = n_always; h->always_doubles = always_doubles;
@@ -1783,6 +2108,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     else if (h->broad_block == 256) e = broad_grid<256>(h, &bgrid);
     else e = broad_grid<512>(h, &bgrid);
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
+    const bool use_grid = h->accel && h->grid_ok;
     unsigned sgrid = (unsigned)h->cu_count * 16u;
     if (const char* e = getenv("RT_SHADE_GRID")) sgrid = (unsigned)h->cu_count * (unsigned)atoi(e);
     h->last_streams = 0;
@@ -1833,7 +2159,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 WfParams& w = wp[p];
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
-                if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
+                if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
+                else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);
                 if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
@@ -1899,6 +2226,13 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
     h->timing.overflow_rays = ctrl[6];
+#if WALK_DEBUG
+    {
+        unsigned dbg[8];
+        hipMemcpy(dbg, h->d_ctrl + 8, sizeof(dbg), hipMemcpyDeviceToHost);
+        fprintf(stderr, "walk: non-finite %u  far %u  list full %u  cells visited %u  items tested %u  (rays %llu)\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], (unsigned long long)r);
+    }
+#endif
 #if SHADE_PROFILE
     {
         unsigned long long prof[6];

@@ -52,13 +52,23 @@ class FrameGatherer:
             self.recv = [torch.empty_like(self.local) for _ in range(world)] if world > 1 else None
         else:
             self.frame, self.index, self.recv = None, None, None
+        # a gloo group moves host memory: device buffers are staged through the host around the collective
+        # (CPU tests, and rehearsals of the multi-rank flow on one GPU); RCCL ("nccl") takes them as they are
+        self.stage = world > 1 and torch.device(device).type != "cpu" and dist.get_backend() == "gloo"
 
     def gather(self):
         """Collective.  Returns the frame tensor [height, width*channels] on rank 0, None elsewhere."""
         if self.world == 1:
             self.frame.index_copy_(0, self.index[0], self.local[: len(self.index[0])])
             return self.frame
-        dist.gather(self.local, self.recv if self.rank == 0 else None, dst=0)
+        if self.stage:
+            recv = [torch.empty(self.local.shape, dtype=self.dtype) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.local.cpu(), recv, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.recv[r].copy_(recv[r])
+        else:
+            dist.gather(self.local, self.recv if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         for r in range(self.world):
@@ -110,6 +120,6 @@ def sum_over_ranks(value: int, device, world: int) -> int:
     """Ray counters: the reference sums long num_rays[T] (main.cpp:321-324); here one all-reduce."""
     if world == 1:
         return int(value)
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
