@@ -1037,7 +1037,10 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
             if (has_next) {
                 const float oo = ax == 0 ? o[0] : (ax == 1 ? o[1] : o[2]);
                 const float iv = ax == 0 ? inv[0] : (ax == 1 ? inv[1] : inv[2]);
-                const float tn = (grid_bound(g, ax, c + (st > 0 ? 1 : 0)) - oo) * iv;
+                // (the axis is a run-time value: selects, not indexing, keep the grid's parameters in scalar registers)
+                const float cs = ax == 0 ? g.cell[0] : (ax == 1 ? g.cell[1] : g.cell[2]);
+                const float gl = ax == 0 ? g.lo[0] : (ax == 1 ? g.lo[1] : g.lo[2]);
+                const float tn = (__builtin_fmaf((float)(c + (st > 0 ? 1 : 0)), cs, gl) - oo) * iv;
                 if (ax == 0) { cell[0] = c; tmax[0] = tn; } else if (ax == 1) { cell[1] = c; tmax[1] = tn; } else { cell[2] = c; tmax[2] = tn; }
                 ci = (unsigned)((cell[2] * g.n[1] + cell[1]) * g.n[0] + cell[0]);
                 n0 = g.cells[2 * (size_t)ci]; n1 = g.cells[2 * (size_t)ci + 1];
