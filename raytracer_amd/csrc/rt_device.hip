@@ -64,24 +64,31 @@ constexpr float F32_U = 5.9604645e-8f;         // 2^-24, unit roundoff of float
 
 struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to a multiple of 32
 
-struct PrimD {               // 96 bytes, indexed by file order: the narrow phase's exact data
+// The exact phase reads these tables lane by lane at unrelated addresses (each lane its own solid or material), and
+// the vector L1 then handles one request per lane and instruction whatever its width.  The records are therefore
+// aligned and ordered so that what a test needs comes in few 16-byte loads (ld2 / ldi4 below).
+struct alignas(32) PrimD {   // 96 bytes, indexed by file order: the narrow phase's exact data
     double a[3];             // sphere centre | plane point | face verts[0]
     double radius;
-    double n[3];             // plane / face unit normal
     int kind, mat0, mat1, voff;
     int vcnt, pad0, pad1, pad2;
+    double n[3];             // plane / face unit normal
+    double pad3;
 };
 
 // One face vertex with the two quantities Face::intersect (geometry.cpp:162-166) derives from the vertex
 // list for every ray: e = v_i - v_i+1 and to_next = e.(v_i - v_i+2), computed once on the host with the
 // same double operations.
-struct FaceV { double v[3]; double e[3]; double to_next; double pad; };
+struct alignas(32) FaceV { double v[3]; double e[3]; double to_next; double pad; };
 
-struct MatD {                // struct Material (geometry.hpp:18-29) in double
-    double ref[3], diff[3], spec[3], rdiff[3], rspec[3];
-    double sexp, rindex;
+struct alignas(16) MatD {    // struct Material (geometry.hpp:18-29) in double, 144 bytes
     unsigned is_light;
     unsigned gloss_thr;      // glossy iff rng < gloss_thr  (= ceil(gloss * 2147483646), main.cpp:48)
+    double rindex;           // the three above: what a hit decides on, one 16-byte load
+    double sexp;
+    double ref[3];
+    double diff[3], spec[3];     // 48 bytes from offset 48
+    double rdiff[3], rspec[3];   // 48 bytes from offset 96
 };
 
 struct KParams {
@@ -144,6 +151,11 @@ DEV bool dvalid(d3 p) {
     return !(dnan(p.x) || dnan(p.y) || dnan(p.z) || p.x == inf || p.y == inf || p.z == inf);
 }
 
+// 16-byte loads and stores of table records (addresses 16-byte aligned by the records' layout)
+DEV double2 ld2(const double* p) { return *(const double2*)p; }
+DEV void st2(double* p, double a, double b) { *(double2*)p = make_double2(a, b); }
+DEV int4 ldi4(const int* p) { return *(const int4*)p; }
+
 // minstd_rand0: x <- 16807 x mod (2^31 - 1), by folding the 46-bit product (2^31 == 1 mod m)
 DEV unsigned rng_next(unsigned& s) {
     unsigned long long p = (unsigned long long)s * 16807ull;
@@ -198,10 +210,10 @@ DEV void consider(d3 p, int idx, d3 o, Hit& h) {
 }
 
 // Sphere::intersect, geometry.cpp:129-138
-DEV d3 sphere_point(const PrimD& s, d3 o, d3 d) {
-    d3 oc = dsub(o, dmk(s.a[0], s.a[1], s.a[2]));
+DEV d3 sphere_point(d3 centre, double radius, d3 o, d3 d) {
+    d3 oc = dsub(o, centre);
     double b = 2.0 * ddot(d, oc);
-    double c = ddot(oc, oc) - s.radius * s.radius;
+    double c = ddot(oc, oc) - radius * radius;
     // Origin outside and centre behind: with b > 0 and c > 0 the rounded sqrt(b*b - 4c) cannot exceed b
     // (sqrt(fl(b*b)) rounds to b), so both roots fail t >= 0.001 and the reference returns a NaN point too.
     if (b > 0.0 && c > 0.0) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
@@ -223,16 +235,15 @@ DEV d3 plane_point(d3 P, d3 n, d3 o, d3 d) {
     return dalong(o, t, d);
 }
 // Face::intersect, geometry.cpp:160-168
-DEV d3 face_point(const PrimD& f, const FaceV* verts, d3 o, d3 d) {
-    d3 p = plane_point(dmk(f.a[0], f.a[1], f.a[2]), dmk(f.n[0], f.n[1], f.n[2]), o, d);
+DEV d3 face_point(d3 a, d3 n, int num, const FaceV* v, d3 o, d3 d) {
+    d3 p = plane_point(a, n, o, d);
     if (dnan(p.x)) return p;                 // plane missed: every comparison below would be false anyway
-    const int num = f.vcnt;
-    const FaceV* v = verts + f.voff;
     bool miss = false;
     for (int i = 0; i < num; i++) {
-        const FaceV fv = v[i];
-        double to_p = ddot(dmk(fv.e[0], fv.e[1], fv.e[2]), dsub(dmk(fv.v[0], fv.v[1], fv.v[2]), p));
-        if (to_p * fv.to_next < 0.0) miss = true;
+        const double* f = v[i].v;
+        const double2 q0 = ld2(f), q1 = ld2(f + 2), q2 = ld2(f + 4), q3 = ld2(f + 6);   // v0 v1 | v2 e0 | e1 e2 | to_next -
+        double to_p = ddot(dmk(q1.y, q2.x, q2.y), dsub(dmk(q0.x, q0.y, q1.x), p));
+        if (to_p * q3.x < 0.0) miss = true;
     }
     if (miss) return dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
     return p;
@@ -257,16 +268,16 @@ DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
 // branch (:48-77, power-cosine lobe about the mirror direction, rejection loop) and the diffuse branch
 // (:78-103, uniform hemisphere about the normal) build their sample the same way about different axes;
 // they share one instruction stream here, each lane keeping its own branch's operation sequence.
-DEV d3 reflection_dir(d3 d, d3 normal, const MatD& m, unsigned& rng, unsigned* err, unsigned item) {
+DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double sexp, unsigned& rng, unsigned* err, unsigned item) {
     const double PI = 3.14159265358979323846;
     const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
-    const bool glossy = rng_next(rng) < m.gloss_thr;
+    const bool glossy = rng_next(rng) < gloss_thr;
     const d3 axis = glossy ? dneg(reflect_dir(d, normal)) : normal;
     const double theta = rtm::acosd(axis.z);
     const d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), axis));
     double sint, cost;
     rtm::sincosd(theta, &sint, &cost);
-    const double inv_exp = 1.0 / m.sexp;
+    const double inv_exp = 1.0 / sexp;
     d3 nd = dmk(0.0, 0.0, 0.0);
     for (int iter = 0;; iter++) {
         const double u1 = rng_uniform(rng);
@@ -298,14 +309,14 @@ DEV d3 refraction_dir(d3 d, d3 normal, double rindex, double n_cur) {
 }
 
 // Plane::get_material, geometry.cpp:106-116
-DEV int plane_material(const PrimD& pi, d3 p) {
-    double vx = p.x - pi.a[0], vz = p.z - pi.a[2];
+DEV int plane_material(double ax, double az, int mat0, int mat1, d3 p) {
+    double vx = p.x - ax, vz = p.z - az;
     int x = (int)(vx / 5.0) % 2;
     int z = (int)(vz / 5.0) % 2;
     if (vx < 0.0) x = -x;
     if (vz < 0.0) z = -z;
-    int m = (x == z) ? pi.mat0 : pi.mat1;
-    if ((vx < 0.0) != (vz < 0.0)) m = (x == z) ? pi.mat1 : pi.mat0;
+    int m = (x == z) ? mat0 : mat1;
+    if ((vx < 0.0) != (vz < 0.0)) m = (x == z) ? mat1 : mat0;
     return m;
 }
 
@@ -380,11 +391,24 @@ struct PathState {
 };
 
 // the stack of per-vertex throughput factors: element (k, c) lives at base[(3k + c) * stride]
-struct FactorStack {
+struct FactorStack {             // single-kernel renderer: a lane's private array
     double* base;
     size_t stride;
-    DEV double get(int k, int c) const { return base[(size_t)(3 * k + c) * stride]; }
-    DEV void set(int k, int c, double v) const { base[(size_t)(3 * k + c) * stride] = v; }
+    DEV void get3(int k, double& a, double& b, double& c) const {
+        a = base[(size_t)(3 * k) * stride]; b = base[(size_t)(3 * k + 1) * stride]; c = base[(size_t)(3 * k + 2) * stride];
+    }
+    DEV void set3(int k, double a, double b, double c) const {
+        base[(size_t)(3 * k) * stride] = a; base[(size_t)(3 * k + 1) * stride] = b; base[(size_t)(3 * k + 2) * stride] = c;
+    }
+};
+// pipeline: the pixel slot's entries are contiguous, 4 doubles (32 bytes) each: two 16-byte accesses per entry
+struct FactorStackV {
+    double* base;
+    DEV void get3(int k, double& a, double& b, double& c) const {
+        const double2 x = ld2(base + 4 * k), y = ld2(base + 4 * k + 2);
+        a = x.x; b = x.y; c = y.x;
+    }
+    DEV void set3(int k, double a, double b, double c) const { st2(base + 4 * k, a, b); st2(base + 4 * k + 2, c, 0.0); }
 };
 
 // the camera ray of do_rays_i, main.cpp:255-270
@@ -443,7 +467,8 @@ DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, 
 // One segment of add_to_path (main.cpp:126-183) after its closest hit `h` is known: record the hit id
 // of a camera ray, push the previous vertex's throughput factor (Path::trace, geometry.cpp:190-213),
 // then terminate the path or sample the next ray.  Returns false when the lane's item is finished.
-DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned item, unsigned long long item_rays,
+template <class FStack>
+DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, unsigned long long item_rays,
                  const KParams& kp) {
     if (s.flags & FL_FIRST_SEG) {
         if (kp.hit_ids) kp.hit_ids[(size_t)s.out_index * kp.spp + s.sample] = h.idx;
@@ -451,29 +476,38 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
     }
     if (h.idx < 0) return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);           // main.cpp:179-182
     const PrimD* pi = kp.prims + h.idx;
-    const int kind = pi->kind;
+    const int4 ids = ldi4(&pi->kind);                  // kind, mat0, mat1, voff
+    const int kind = ids.x;
     d3 normal;
-    int mi;
-    if (kind == RT_KIND_SPHERE) { normal = dnorm(dsub(h.p, dmk(pi->a[0], pi->a[1], pi->a[2]))); mi = pi->mat0; }
-    else if (kind == RT_KIND_PLANE) { normal = dmk(pi->n[0], pi->n[1], pi->n[2]); mi = plane_material(*pi, h.p); }
-    else { normal = dmk(pi->n[0], pi->n[1], pi->n[2]); mi = pi->mat0; }
+    int mi = ids.y;
+    if (kind == RT_KIND_SPHERE) {
+        const double2 a01 = ld2(pi->a), a2r = ld2(pi->a + 2);
+        normal = dnorm(dsub(h.p, dmk(a01.x, a01.y, a2r.x)));
+    } else {
+        const double2 n01 = ld2(pi->n), n2p = ld2(pi->n + 2);
+        normal = dmk(n01.x, n01.y, n2p.x);
+        if (kind == RT_KIND_PLANE) mi = plane_material(pi->a[0], pi->a[2], ids.y, ids.z, h.p);
+    }
     const MatD* m = kp.mats + mi;
-    const bool is_light = m->is_light != 0;
+    const int4 mq = ldi4((const int*)m);               // is_light, gloss_thr, rindex (two words)
+    const bool is_light = mq.x != 0;
+    const unsigned gloss_thr = (unsigned)mq.y;
+    const double rindex = __hiloint2double(mq.w, mq.z);
     const bool dead_end = (!is_light) && s.remaining == 0 && kp.has_light;             // main.cpp:137-153: always black
 
     if (s.nverts > 0 && !dead_end) {
         const MatD* pm = kp.mats + s.pv_mat;
         d3 w = dnorm(dsub(h.p, s.o));
         double sp;
-        const double *dc, *sc;
-        if (s.flags & FL_PV_REFLECT) { sp = rtm::powd(ddot(s.pv_r, w), pm->sexp); dc = pm->diff; sc = pm->spec; }
-        else { sp = 1.0; dc = pm->rdiff; sc = pm->rspec; }
+        const bool pv_reflect = (s.flags & FL_PV_REFLECT) != 0;
+        const double* cs = pv_reflect ? pm->diff : pm->rdiff;       // (diffuse, specular) or the refraction pair
+        const double2 c01 = ld2(cs), c2s0 = ld2(cs + 2), s12 = ld2(cs + 4);
+        if (pv_reflect) sp = rtm::powd(ddot(s.pv_r, w), pm->sexp);
+        else sp = 1.0;
         double dd = ddot(s.pv_n, w);
         if (sp < 0.0) sp = 0.0;
         if (dd < 0.0) dd = 0.0;
-        fst.set(s.nverts - 1, 0, dc[0] * dd + sc[0] * sp);
-        fst.set(s.nverts - 1, 1, dc[1] * dd + sc[1] * sp);
-        fst.set(s.nverts - 1, 2, dc[2] * dd + sc[2] * sp);
+        fst.set3(s.nverts - 1, c01.x * dd + c2s0.y * sp, c01.y * dd + s12.x * sp, c2s0.x * dd + s12.y * sp);
     }
 
     // how the segment ends; every terminating case funnels into ONE end_path call below so that the lanes
@@ -481,9 +515,12 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
     bool term = false;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (is_light) {                                                                    // main.cpp:132-135
-        c0 = m->ref[0]; c1 = m->ref[1]; c2 = m->ref[2];
+        const double2 e0 = ld2(&m->sexp), e12 = ld2(m->ref + 1);     // (sexp, ref0), (ref1, ref2)
+        c0 = e0.y; c1 = e12.x; c2 = e12.y;
         for (int k = s.nverts - 1; k >= 0; k--) {
-            c0 = c0 * fst.get(k, 0); c1 = c1 * fst.get(k, 1); c2 = c2 * fst.get(k, 2);
+            double f0, f1, f2;
+            fst.get3(k, f0, f1, f2);
+            c0 = c0 * f0; c1 = c1 * f1; c2 = c2 * f2;
         }
         term = true;
     } else if (dead_end) {
@@ -497,12 +534,11 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
         int change = 1;
         double n2 = 1.0;
         bool reflect = false;
-        const double rindex = m->rindex;
         if (__builtin_fabs(rindex - s.n_cur) < 0.0001) {                               // leaving, main.cpp:158-161
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
             change = 0;
         } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                   // main.cpp:164-167
-            fwd = reflection_dir(s.d, normal, *m, s.rng, &kp.ctrl[1], item);
+            fwd = reflection_dir(s.d, normal, gloss_thr, m->sexp, s.rng, &kp.ctrl[1], item);
             reflect = true;
         } else {                                                                       // main.cpp:168-171
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
@@ -522,10 +558,14 @@ DEV bool segment(PathState& s, const Hit& h, const FactorStack& fst, unsigned it
 // narrow phase on one candidate: the reference's double-precision test
 DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
     const PrimD* pr = prims + idx;
-    const int kind = pr->kind;
-    if (kind == RT_KIND_SPHERE) return sphere_point(*pr, o, d);
-    if (kind == RT_KIND_PLANE) return plane_point(dmk(pr->a[0], pr->a[1], pr->a[2]), dmk(pr->n[0], pr->n[1], pr->n[2]), o, d);
-    return face_point(*pr, verts, o, d);
+    const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
+    const double2 a01 = ld2(pr->a), a2r = ld2(pr->a + 2);
+    const d3 a = dmk(a01.x, a01.y, a2r.x);
+    if (ids.x == RT_KIND_SPHERE) return sphere_point(a, a2r.y, o, d);
+    const double2 n01 = ld2(pr->n), n2p = ld2(pr->n + 2);
+    const d3 n = dmk(n01.x, n01.y, n2p.x);
+    if (ids.x == RT_KIND_PLANE) return plane_point(a, n, o, d);
+    return face_point(a, n, pr->vcnt, verts + ids.w, o, d);
 }
 DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) { consider(narrow_point(idx, o, d, kp.prims, kp.verts), idx, o, h); }
 
@@ -540,9 +580,7 @@ DEV void narrow_always(const double* tab, int n_always, d3 o, d3 d, Hit& h) {
         const int nv = __builtin_amdgcn_readfirstlane((int)r[2]);
         d3 p0;
         if (kind == RT_KIND_SPHERE) {
-            PrimD s;
-            s.a[0] = r[4]; s.a[1] = r[5]; s.a[2] = r[6]; s.radius = r[7];
-            p0 = sphere_point(s, o, d);
+            p0 = sphere_point(dmk(r[4], r[5], r[6]), r[7], o, d);
         } else {
             p0 = plane_point(dmk(r[4], r[5], r[6]), dmk(r[8], r[9], r[10]), o, d);
             if (kind == RT_KIND_FACE && !dnan(p0.x)) {
@@ -755,11 +793,12 @@ struct WfParams {
     int* si[2];                // [SI_COUNT][slots] by queue position, one copy per queue: a surviving ray's state moves
     double* sd[2];             // [SD_COUNT][slots]   with it to its place in the next queue, so both sides are coalesced
     double* acc;               // [3][slots] radiance sum of the slot's pixel (used when paths_per_pixel > 1)
-    double* stack;             // [3*max_verts][slots]
+    double* stack;             // [slots][max_verts][4]: throughput factors of the slot's path, 32 bytes per vertex
     unsigned* queue[2];        // slot ids of the live rays, by queue position
     unsigned* counts;          // counts[i] = live rays entering iteration i
     float4* rec[2];            // ray records by queue position
-    uint2* cand;               // [slots][WF_CAND_CAP] by queue position: (word index j, keep mask of records 32j..32j+31,
+    uint2* cand;               // [WF_CAND_CAP][slots]: entry e of the ray at queue position pos is cand[e * slots + pos]
+                               // (neighbouring lanes read neighbouring words): (word index j, keep mask of records 32j..32j+31,
                                // bit 31-k = record 32j+k), only the non-zero words, ascending j
     unsigned* cand_cnt;        // [slots] entries used; WF_OVERFLOW = more than WF_CAND_CAP non-zero words
 };
@@ -867,8 +906,9 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
             const float thrA = bA.w, thrB = bB.w;
             unsigned nA = 0, nB = 0;
             if (c > 0) { if (vA) nA = w.cand_cnt[pA]; if (vB) nB = w.cand_cnt[pB]; }
-            uint2* outA = w.cand + (size_t)pA * WF_CAND_CAP;
-            uint2* outB = w.cand + (size_t)pB * WF_CAND_CAP;
+            uint2* outA = w.cand + pA;
+            uint2* outB = w.cand + pB;
+            const size_t cstride = w.slots;
             for (int g = 0; g < ch.count; g += BROAD_GROUP) {
                 unsigned mA = 0, mB = 0;
 #pragma unroll 1
@@ -885,10 +925,10 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
                 // append the non-zero words to the ray's list (idle lanes never store)
                 const unsigned j = (unsigned)(word0 + g / BROAD_GROUP);
                 if (mA != 0u && vA && nA != WF_OVERFLOW) {
-                    if (nA < (unsigned)WF_CAND_CAP) { outA[nA] = make_uint2(j, mA); nA++; } else nA = WF_OVERFLOW;
+                    if (nA < (unsigned)WF_CAND_CAP) { outA[nA * cstride] = make_uint2(j, mA); nA++; } else nA = WF_OVERFLOW;
                 }
                 if (mB != 0u && vB && nB != WF_OVERFLOW) {
-                    if (nB < (unsigned)WF_CAND_CAP) { outB[nB] = make_uint2(j, mB); nB++; } else nB = WF_OVERFLOW;
+                    if (nB < (unsigned)WF_CAND_CAP) { outB[nB * cstride] = make_uint2(j, mB); nB++; } else nB = WF_OVERFLOW;
                 }
             }
             if (vA) w.cand_cnt[pA] = nA;
@@ -941,7 +981,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
     const float inf = __builtin_inff();
     for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
         const float4 ra = w.rec[0][pos], rb = w.rec[1][pos];
-        uint2* out = w.cand + (size_t)pos * WF_CAND_CAP;
+        uint2* out = w.cand + pos;
+        const size_t cstride = w.slots;
         const float o[3] = {0.5f * rb.x, 0.5f * rb.y, 0.5f * rb.z};
         const float d[3] = {-ra.x * (1.0f / BROAD_SCALE), -ra.y * (1.0f / BROAD_SCALE), -ra.z * (1.0f / BROAD_SCALE)};
         const float thr = rb.w;
@@ -996,7 +1037,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
             const unsigned j = idx / (unsigned)BROAD_GROUP, bit = 0x80000000u >> (idx % (unsigned)BROAD_GROUP);
             if (j == cur_j) cur_m |= bit;
             else {
-                if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) out[n++] = make_uint2(cur_j, cur_m); else n = WF_OVERFLOW; }
+                if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) { out[n * cstride] = make_uint2(cur_j, cur_m); n++; } else n = WF_OVERFLOW; }
                 cur_j = j; cur_m = bit;
             }
             if (r2 >= 0.0f) {
@@ -1059,7 +1100,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
             if (!has_next || texit - g.pad > tU) break;
             c0 = n0; c1 = n1;
         }
-        if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) out[n++] = make_uint2(cur_j, cur_m); else n = WF_OVERFLOW; }
+        if (cur_m != 0u && n != WF_OVERFLOW) { if (n < (unsigned)WF_CAND_CAP) { out[n * cstride] = make_uint2(cur_j, cur_m); n++; } else n = WF_OVERFLOW; }
 #if WALK_DEBUG
         if (n == WF_OVERFLOW) atomicAdd(&w.kp.ctrl[10], 1u);
         atomicAdd(&w.kp.ctrl[11], (unsigned)nsteps);
@@ -1085,18 +1126,19 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
     h.q = __builtin_inf(); h.idx = -1;
     h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
     const unsigned n = live ? w.cand_cnt[pos] : 0u;
-    const uint2* cl = w.cand + (size_t)pos * WF_CAND_CAP;
+    const uint2* cl = w.cand + pos;
+    const size_t cstride = w.slots;
     bool heavy = (n == WF_OVERFLOW);
     if (!heavy && n > HEAVY_WORDS) {
         unsigned c = 0;
-        for (unsigned e = 0; e < n; e++) c += (unsigned)__popc(cl[e].y);
+        for (unsigned e = 0; e < n; e++) c += (unsigned)__popc(cl[e * cstride].y);
         heavy = c > HEAVY_BITS;
     }
     if (live && !heavy) {
         narrow_always(alw, w.kp.n_always, o, d, h);
         ncand_total += (unsigned)w.kp.n_always;
         for (unsigned e = 0; e < n; e++) {
-            const uint2 ent = cl[e];
+            const uint2 ent = cl[e * cstride];
             unsigned m = ent.y;
             ncand_total += (unsigned)__popc(m);
             while (m) {
@@ -1178,7 +1220,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             slot = w.queue[qi][pos];
             load_state(w, qi, pos, slot, s);
             nrays++;
-            FactorStack fst; fst.base = w.stack + slot; fst.stride = w.slots;
+            FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
         }
         SHADE_TICK(2);
@@ -2057,7 +2099,7 @@ static int ensure_pipeline(rt_handle h, rt_context::PipeBufs& b, size_t slots, i
     }
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.si[q], slots * SI_COUNT * sizeof(int)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.sd[q], slots * SD_COUNT * sizeof(double)));
-    HIP_TRY(h, hipMalloc((void**)&b.stack, slots * (size_t)verts * 3 * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void**)&b.stack, slots * (size_t)verts * 4 * sizeof(double)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.queue[q], slots * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc((void**)&b.counts, ((size_t)iters + 2) * sizeof(unsigned)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.rec[q], slots * sizeof(float4)));

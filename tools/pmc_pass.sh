@@ -10,6 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 k=0
 for pass in "$@"; do
   k=$((k+1))
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pass$k -o vm -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --roofline-frames 0 > $out/pass$k.log 2>&1 || { echo "pass $k failed"; tail -5 $out/pass$k.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pass$k -o vm -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-walk --roofline-frames 0 > $out/pass$k.log 2>&1 || { echo "pass $k failed"; tail -5 $out/pass$k.log; exit 1; }
 done
 python $root/tools/pmc_summary.py $out | grep -v "at::\|rocclr\|set_count\|elementwise"
