@@ -782,7 +782,8 @@ constexpr unsigned WF_OVERFLOW = 0xffffffffu;
 // Not stored: pixel coordinates (a function of the slot), the current refraction index (1, or the index of the
 // previous vertex's material when the path is inside a solid: a flag).
 enum { SI_RNG = 0, SI_SAMPLE, SI_PACK, SI_PVMAT, SI_COUNT };     // PACK = remaining (signed 8) | nverts << 8 | flags << 16
-enum { SD_O = 0, SD_D = 3, SD_PVN = 6, SD_PVR = 9, SD_COUNT = 12 };
+// the 12 doubles as 6 arrays of pairs (16-byte accesses): (o.x o.y) (o.z d.x) (d.y d.z) (pvn.x pvn.y) (pvn.z pvr.x) (pvr.y pvr.z)
+enum { SD_COUNT = 12, SD_PAIRS = 6 };
 enum { FL_INSIDE = 4 };
 
 struct WfParams {
@@ -791,7 +792,7 @@ struct WfParams {
     unsigned item_base;        // first local pixel index of the batch
     int iter;                  // iteration number: queue iter&1 is read, (iter+1)&1 written
     int* si[2];                // [SI_COUNT][slots] by queue position, one copy per queue: a surviving ray's state moves
-    double* sd[2];             // [SD_COUNT][slots]   with it to its place in the next queue, so both sides are coalesced
+    double2* sd[2];            // [SD_PAIRS][slots]   with it to its place in the next queue, so both sides are coalesced
     double* acc;               // [3][slots] radiance sum of the slot's pixel (used when paths_per_pixel > 1)
     double* stack;             // [slots][max_verts][4]: throughput factors of the slot's path, 32 bytes per vertex
     unsigned* queue[2];        // slot ids of the live rays, by queue position
@@ -803,7 +804,8 @@ struct WfParams {
     unsigned* cand_cnt;        // [slots] entries used; WF_OVERFLOW = more than WF_CAND_CAP non-zero words
 };
 
-DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, PathState& s) {
+// the ray itself (o, d) was read before the closest-hit search and is passed in
+DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, d3 ro, d3 rd, PathState& s) {
     const size_t n = w.slots;
     const int* si = w.si[q] + pos;
     s.rng = (unsigned)si[SI_RNG * n];
@@ -818,11 +820,12 @@ DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, PathS
     s.n_cur = (s.flags & FL_INSIDE) ? w.kp.mats[s.pv_mat].rindex : 1.0;
     s.acc0 = s.acc1 = s.acc2 = 0.0;
     s.acc_mem = w.acc + slot; s.acc_stride = n;
-    const double* d = w.sd[q] + pos;
-    s.o = dmk(d[(SD_O + 0) * n], d[(SD_O + 1) * n], d[(SD_O + 2) * n]);
-    s.d = dmk(d[(SD_D + 0) * n], d[(SD_D + 1) * n], d[(SD_D + 2) * n]);
-    s.pv_n = dmk(d[(SD_PVN + 0) * n], d[(SD_PVN + 1) * n], d[(SD_PVN + 2) * n]);
-    s.pv_r = dmk(d[(SD_PVR + 0) * n], d[(SD_PVR + 1) * n], d[(SD_PVR + 2) * n]);
+    const double2* d = w.sd[q] + pos;
+    const double2 p3 = d[3 * n], p4 = d[4 * n], p5 = d[5 * n];
+    s.o = ro;
+    s.d = rd;
+    s.pv_n = dmk(p3.x, p3.y, p4.x);
+    s.pv_r = dmk(p4.y, p5.x, p5.y);
 }
 
 DEV void store_state(const WfParams& w, int q, unsigned pos, const PathState& s) {
@@ -834,11 +837,9 @@ DEV void store_state(const WfParams& w, int q, unsigned pos, const PathState& s)
     const int flags = (s.flags & (FL_FIRST_SEG | FL_PV_REFLECT)) | ((s.n_cur != 1.0) ? FL_INSIDE : 0);
     si[SI_PACK * n] = (s.remaining & 0xff) | ((s.nverts & 0xff) << 8) | (flags << 16);
     si[SI_PVMAT * n] = s.pv_mat;
-    double* d = w.sd[q] + pos;
-    d[(SD_O + 0) * n] = s.o.x; d[(SD_O + 1) * n] = s.o.y; d[(SD_O + 2) * n] = s.o.z;
-    d[(SD_D + 0) * n] = s.d.x; d[(SD_D + 1) * n] = s.d.y; d[(SD_D + 2) * n] = s.d.z;
-    d[(SD_PVN + 0) * n] = s.pv_n.x; d[(SD_PVN + 1) * n] = s.pv_n.y; d[(SD_PVN + 2) * n] = s.pv_n.z;
-    d[(SD_PVR + 0) * n] = s.pv_r.x; d[(SD_PVR + 1) * n] = s.pv_r.y; d[(SD_PVR + 2) * n] = s.pv_r.z;
+    double2* d = w.sd[q] + pos;
+    d[0] = make_double2(s.o.x, s.o.y); d[n] = make_double2(s.o.z, s.d.x); d[2 * n] = make_double2(s.d.y, s.d.z);
+    d[3 * n] = make_double2(s.pv_n.x, s.pv_n.y); d[4 * n] = make_double2(s.pv_n.z, s.pv_r.x); d[5 * n] = make_double2(s.pv_r.y, s.pv_r.z);
 }
 
 DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathState& s, int q) {
@@ -1209,16 +1210,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
         d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
         if (live) {
-            const double* sd = w.sd[qi] + pos;
+            const double2* sd = w.sd[qi] + pos;
             const size_t n = w.slots;
-            ro = dmk(sd[(SD_O + 0) * n], sd[(SD_O + 1) * n], sd[(SD_O + 2) * n]);
-            rd = dmk(sd[(SD_D + 0) * n], sd[(SD_D + 1) * n], sd[(SD_D + 2) * n]);
+            const double2 p0 = sd[0], p1 = sd[n], p2 = sd[2 * n];
+            ro = dmk(p0.x, p0.y, p1.x);
+            rd = dmk(p1.y, p2.x, p2.y);
         }
         const Hit h = find_hit(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         if (live) {
             slot = w.queue[qi][pos];
-            load_state(w, qi, pos, slot, s);
+            load_state(w, qi, pos, slot, ro, rd, s);
             nrays++;
             FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
@@ -1400,7 +1402,7 @@ struct rt_context {
     // stack entries
     struct PipeBufs {
         size_t slots = 0; int verts = 0; int iters = 0;
-        int* si[2] = {nullptr, nullptr}; double* sd[2] = {nullptr, nullptr}; double* stack = nullptr; double* acc = nullptr;
+        int* si[2] = {nullptr, nullptr}; double2* sd[2] = {nullptr, nullptr}; double* stack = nullptr; double* acc = nullptr;
         unsigned* queue[2] = {nullptr, nullptr};
         unsigned* counts = nullptr;
         float4* rec[2] = {nullptr, nullptr};
