@@ -558,9 +558,12 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
 // narrow phase on one candidate: the reference's double-precision test
 DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
     const PrimD* pr = prims + idx;
-    const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
     const double2 a01 = ld2(pr->a), a2r = ld2(pr->a + 2);
     const d3 a = dmk(a01.x, a01.y, a2r.x);
+    // the table holds a NaN radius for planes and faces: a number means a sphere, with no further read (a sphere
+    // whose own radius is NaN takes the long way round and is still tested as a sphere)
+    if (a2r.y == a2r.y) return sphere_point(a, a2r.y, o, d);
+    const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
     if (ids.x == RT_KIND_SPHERE) return sphere_point(a, a2r.y, o, d);
     const double2 n01 = ld2(pr->n), n2p = ld2(pr->n + 2);
     const d3 n = dmk(n01.x, n01.y, n2p.x);
@@ -765,11 +768,13 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
 #ifndef WALK_DEBUG
 #define WALK_DEBUG 0
 #endif
+// shade_kernel workgroup: 256 threads.  Larger groups mean fewer queue atomics but longer waits at the compaction
+// barrier (with 16-byte table reads in place: 512 threads 4.65 ms, 256 threads 4.40 ms, 128 threads 4.5 ms per C3 frame)
 #ifndef SHADE_BLOCK
-#define SHADE_BLOCK 512
+#define SHADE_BLOCK 256
 #endif
 #ifndef SHADE_WAVES
-#define SHADE_WAVES 8
+#define SHADE_WAVES 4
 #endif
 constexpr int BROAD_GROUP = 32;        // records per candidate-mask word; LDS windows are multiples of it
 constexpr int BROAD_INNER = 8;         // records loaded from LDS per inner step of broad_kernel
@@ -1820,7 +1825,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         PrimD& q = pd[i];
         q.kind = kind; q.mat0 = m0; q.mat1 = m1;
         for (int k = 0; k < 3; k++) { q.a[k] = p[RT_PR_A + k]; q.n[k] = p[RT_PR_N + k]; }
-        q.radius = p[RT_PR_RADIUS];
+        q.radius = kind == RT_KIND_SPHERE ? p[RT_PR_RADIUS] : (double)NAN;   // see narrow_point
         if (p[RT_PR_LIGHT] != 0.0 && first_light < 0) first_light = i;
         bool bounded = false;
         if (kind == RT_KIND_SPHERE) {
