@@ -35,6 +35,15 @@ for row in csv.DictReader(open(os.path.join(src, 'trace', 'vm_kernel_stats.csv')
     tot = float(row['TotalDurationNs']) / 1e6
     lines.append('| %s | %s | %.1f | %.2f | %s | %s |' % (short(row['Name']), row['Calls'], float(row['AverageNs']) / 1e3, tot,
                                                          '%.3f' % (tot / frames) if frames else '-', row['Percentage']))
+wk = os.path.join(src, 'trace_walk', 'vm_kernel_stats.csv')
+if os.path.exists(wk):
+    shutil.copy(wk, os.path.join(dst, prefix + '_walk_kernel_stats.csv'))
+    lines += ['', '## the same frames with RT_OPT_ACCEL = 1 (walk_kernel in place of broad_kernel), rocprofv3 --kernel-trace --stats', '',
+              '| kernel | calls | avg us | total ms | ms per frame | % |', '|---|---|---|---|---|---|']
+    for row in csv.DictReader(open(wk)):
+        tot = float(row['TotalDurationNs']) / 1e6
+        lines.append('| %s | %s | %.1f | %.2f | %s | %s |' % (short(row['Name']), row['Calls'], float(row['AverageNs']) / 1e3, tot,
+                                                             '%.3f' % (tot / frames) if frames else '-', row['Percentage']))
 traffic = {}
 lines += ['', '## HBM traffic per frame (separate --pmc passes, 1 frame each)', '',
           '| kernel | launches | FETCH_SIZE KB (raw) | WRITE_SIZE KB | bytes per frame (fetch x2 + write) |', '|---|---|---|---|---|']
