@@ -806,7 +806,7 @@ struct WfParams {
     uint2* cand;               // [WF_CAND_CAP][slots]: entry e of the ray at queue position pos is cand[e * slots + pos]
                                // (neighbouring lanes read neighbouring words): (word index j, keep mask of records 32j..32j+31,
                                // bit 31-k = record 32j+k), only the non-zero words, ascending j
-    unsigned* cand_cnt;        // [slots] entries used; WF_OVERFLOW = more than WF_CAND_CAP non-zero words
+    unsigned* cand_cnt;        // [2][slots] (one per queue: a round's shade_kernel reads one and clears the other) entries used; above WF_CAND_CAP (WF_OVERFLOW as a rule): more non-zero words than fit
 };
 
 // the ray itself (o, d) was read before the closest-hit search and is passed in
@@ -852,6 +852,7 @@ DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathStat
     store_state(w, q, pos, s);
     const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
     w.rec[0][pos] = r.a; w.rec[1][pos] = r.b;
+    w.cand_cnt[(size_t)q * w.slots + pos] = 0u;        // broad_kernel's slices add to it
 }
 
 __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
@@ -890,9 +891,20 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     const int nchunks = w.kp.nchunks;
+    unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
     const unsigned per_block = BLOCK * 2;
     const unsigned nbatches = (count + per_block - 1) / per_block;
-    if (blockIdx.x >= nbatches) return;
+    // A round with fewer batches than workgroups (the late rounds of a frame, every round of a small share of a
+    // frame) would leave most of the chip idle while a few workgroups scan the whole list (about 50 us for 1056
+    // records).  The list is then cut into `slices` runs of mask words and workgroup b scans slice b / nbatches for
+    // batch b % nbatches; the slices of a ray append to its list through an atomic on its (zeroed) entry count.
+    unsigned slices = 1;
+    if (nchunks == 1 && nbatches < gridDim.x) {
+        const unsigned words = (unsigned)w.kp.chunks[0].count / BROAD_GROUP;
+        slices = gridDim.x / nbatches;
+        if (slices > words) slices = words;
+    }
+    if (blockIdx.x >= nbatches * slices) return;
     const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
     for (int c = 0; c < nchunks; c++) {
         const ChunkDesc ch = w.kp.chunks[c];
@@ -903,7 +915,14 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
         }
         __syncthreads();
         const int word0 = ch.first_index / BROAD_GROUP;
-        for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+        const unsigned slice = blockIdx.x / nbatches;
+        int g_begin = 0, g_end = ch.count;
+        if (slices > 1) {
+            const unsigned words = (unsigned)ch.count / BROAD_GROUP;
+            g_begin = (int)(words * slice / slices) * BROAD_GROUP;
+            g_end = (int)(words * (slice + 1) / slices) * BROAD_GROUP;
+        }
+        for (unsigned batch = slices > 1 ? blockIdx.x % nbatches : blockIdx.x; batch < nbatches; batch += slices > 1 ? nbatches : gridDim.x) {
             const unsigned pA = batch * per_block + threadIdx.x, pB = pA + BLOCK;
             const bool vA = pA < count, vB = pB < count;
             // idle lanes carry NaN constants: no bit is ever set for them
@@ -911,11 +930,11 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
             const float4 aB = vB ? w.rec[0][pB] : nan4, bB = vB ? w.rec[1][pB] : nan4;
             const float thrA = bA.w, thrB = bB.w;
             unsigned nA = 0, nB = 0;
-            if (c > 0) { if (vA) nA = w.cand_cnt[pA]; if (vB) nB = w.cand_cnt[pB]; }
+            if (c > 0) { if (vA) nA = cand_cnt[pA]; if (vB) nB = cand_cnt[pB]; }
             uint2* outA = w.cand + pA;
             uint2* outB = w.cand + pB;
             const size_t cstride = w.slots;
-            for (int g = 0; g < ch.count; g += BROAD_GROUP) {
+            for (int g = g_begin; g < g_end; g += BROAD_GROUP) {
                 unsigned mA = 0, mB = 0;
 #pragma unroll 1
                 for (int k0 = 0; k0 < BROAD_GROUP; k0 += BROAD_INNER) {
@@ -930,6 +949,12 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
                 }
                 // append the non-zero words to the ray's list (idle lanes never store)
                 const unsigned j = (unsigned)(word0 + g / BROAD_GROUP);
+                if (slices > 1) {
+                    // shared list: the count may pass the capacity, which marks the list as overflowed
+                    if (mA != 0u && vA) { const unsigned at = atomicAdd(&cand_cnt[pA], 1u); if (at < (unsigned)WF_CAND_CAP) outA[at * cstride] = make_uint2(j, mA); }
+                    if (mB != 0u && vB) { const unsigned at = atomicAdd(&cand_cnt[pB], 1u); if (at < (unsigned)WF_CAND_CAP) outB[at * cstride] = make_uint2(j, mB); }
+                    continue;
+                }
                 if (mA != 0u && vA && nA != WF_OVERFLOW) {
                     if (nA < (unsigned)WF_CAND_CAP) { outA[nA * cstride] = make_uint2(j, mA); nA++; } else nA = WF_OVERFLOW;
                 }
@@ -937,8 +962,10 @@ __global__ __launch_bounds__(BLOCK) void broad_kernel(const WfParams w) {
                     if (nB < (unsigned)WF_CAND_CAP) { outB[nB * cstride] = make_uint2(j, mB); nB++; } else nB = WF_OVERFLOW;
                 }
             }
-            if (vA) w.cand_cnt[pA] = nA;
-            if (vB) w.cand_cnt[pB] = nB;
+            if (slices == 1) {
+                if (vA) cand_cnt[pA] = nA;
+                if (vB) cand_cnt[pB] = nB;
+            }
         }
     }
 }
@@ -984,6 +1011,7 @@ DEV float grid_bound(const GridD& g, int k, int i) { return __builtin_fmaf((floa
 __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD g) {
     const unsigned count = w.counts[w.iter];
     const unsigned stride = gridDim.x * blockDim.x;
+    unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
     const float inf = __builtin_inff();
     for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
         const float4 ra = w.rec[0][pos], rb = w.rec[1][pos];
@@ -999,7 +1027,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
 #if WALK_DEBUG
             atomicAdd(&w.kp.ctrl[!(chk == 0.0f) ? 8 : 9], 1u);
 #endif
-            w.cand_cnt[pos] = WF_OVERFLOW; continue;
+            cand_cnt[pos] = WF_OVERFLOW; continue;
         }
 
         // ---- the ray's interval inside the grid box, and the walk's state
@@ -1021,7 +1049,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
         }
         // the box is larger than every listed solid by 2 pad: a ray that the float interval test puts outside it by
         // more than its own rounding cannot hit any of them
-        if (miss || t0 > t1 * 1.0001f + 4.0f * g.pad) { w.cand_cnt[pos] = 0u; continue; }
+        if (miss || t0 > t1 * 1.0001f + 4.0f * g.pad) { cand_cnt[pos] = 0u; continue; }
         float tmax[3];
         for (int k = 0; k < 3; k++) {
             const float p = __builtin_fmaf(d[k], t0, o[k]);
@@ -1112,7 +1140,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
         atomicAdd(&w.kp.ctrl[11], (unsigned)nsteps);
         atomicAdd(&w.kp.ctrl[12], ntests);
 #endif
-        w.cand_cnt[pos] = n;
+        cand_cnt[pos] = n;
     }
 }
 
@@ -1131,10 +1159,10 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
     Hit h;
     h.q = __builtin_inf(); h.idx = -1;
     h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-    const unsigned n = live ? w.cand_cnt[pos] : 0u;
+    const unsigned n = live ? w.cand_cnt[(size_t)(w.iter & 1) * w.slots + pos] : 0u;
     const uint2* cl = w.cand + pos;
     const size_t cstride = w.slots;
-    bool heavy = (n == WF_OVERFLOW);
+    bool heavy = n > (unsigned)WF_CAND_CAP;     // WF_OVERFLOW, or a shared list's count that passed the capacity
     if (!heavy && n > HEAVY_WORDS) {
         unsigned c = 0;
         for (unsigned e = 0; e < n; e++) c += (unsigned)__popc(cl[e * cstride].y);
@@ -2112,7 +2140,7 @@ static int ensure_pipeline(rt_handle h, rt_context::PipeBufs& b, size_t slots, i
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.rec[q], slots * sizeof(float4)));
     HIP_TRY(h, hipMalloc((void**)&b.acc, slots * 3 * sizeof(double)));
     HIP_TRY(h, hipMalloc((void**)&b.cand, slots * WF_CAND_CAP * sizeof(uint2)));
-    HIP_TRY(h, hipMalloc((void**)&b.cand_cnt, slots * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc((void**)&b.cand_cnt, 2 * slots * sizeof(unsigned)));
     b.slots = slots; b.verts = verts; b.iters = iters;
     return RT_OK;
 }
