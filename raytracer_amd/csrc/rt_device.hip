@@ -1464,7 +1464,7 @@ struct rt_context {
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
     int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
-    double grid_density = 2.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY)
+    double grid_density = 1.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY); 0.5 to 8 measured: flat optimum, 1 best on C4
 };
 
 namespace {
