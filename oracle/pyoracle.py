@@ -17,6 +17,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+REF_KAT = os.path.join(HERE, "_ref", "ref_kat")
 
 POLICY_REF, POLICY_DEV = 0, 1
 RNG_STREAM, RNG_PIXEL = 0, 1
@@ -46,6 +47,8 @@ def lib():
         l.oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         l.oracle_math.restype = None
         l.oracle_math.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+        l.oracle_kat.restype = None
+        l.oracle_kat.argtypes = [dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, dp]
         _lib = l
     return _lib
 
@@ -156,3 +159,37 @@ def run_reference(scene_text, num_threads=-1, num_blurs=-1, timeout=600):
     img = np.frombuffer(b, dtype="<i4", count=W * H, offset=off).reshape(H, W).copy(); off += 4 * W * H
     secs = struct.unpack("<d", b[off:off + 8])[0]
     return dict(rgb=rgb, rays=rays, img=img, seconds=secs, threads=T, blurs=NB)
+
+
+# ------------------------------------------------------------------ function-level known answers
+def kat(scene, rays_in):
+    """oracle_kat: rays_in float64[n,7] (o, d, RNG state) -> records float64[n, 35 + 3*n_prims] in ref_kat's layout."""
+    l = lib()
+    rays_in = np.ascontiguousarray(rays_in, dtype=np.float64)
+    params = scene.params()
+    prims = np.ascontiguousarray(scene.prims, dtype=np.float64)
+    mats = np.ascontiguousarray(scene.mats, dtype=np.float64)
+    verts = np.ascontiguousarray(scene.verts, dtype=np.float64)
+    if verts.size == 0:
+        verts = np.zeros((1, 3))
+    out = np.zeros((len(rays_in), 35 + 3 * len(prims)), dtype=np.float64)
+    l.oracle_kat(_dp(params), len(prims), _dp(prims), len(mats), _dp(mats), len(scene.verts), _dp(verts),
+                 len(rays_in), _dp(rays_in), _dp(out))
+    return out
+
+
+def run_reference_kat(scene_path, n_rays, seed):
+    """Runs oracle/_ref/ref_kat (the reference's own functions).  Returns (records float64[n, 35+3*n_objs],
+    colors float64[512, 5] = r g b max packed)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "kat.bin")
+        subprocess.run([REF_KAT, scene_path, str(int(n_rays)), str(int(seed)), out], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=td)
+        raw = open(out, "rb").read()
+    n, nobj = struct.unpack_from("<ii", raw, 0)
+    stride = 35 + 3 * nobj
+    rec = np.frombuffer(raw, dtype="<f8", count=n * stride, offset=8).reshape(n, stride).copy()
+    off = 8 + 8 * n * stride
+    (nc,) = struct.unpack_from("<i", raw, off)
+    col = np.frombuffer(raw, dtype="<f8", count=nc * 5, offset=off + 4).reshape(nc, 5).copy()
+    return rec, col

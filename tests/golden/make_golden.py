@@ -14,6 +14,10 @@ Outputs:
   small_room.scene.json / small_mixed.scene.json   synthetic scene streams
   small_room_t8_b1.npz / small_mixed_t8_b0.npz     their full 8-bit images
   rng_kat.json              libstdc++ default_random_engine known answers
+  kat.npz                   function-level known answers from oracle/_ref/ref_kat (the reference's own intersect,
+                            get_intersection, get_reflection_ray, get_refraction_ray, add_to_path + Path::trace and
+                            Color::to_int on seeded rays through scene.json, small_room and small_mixed):
+                            records float64[n, 35 + 3*n_objs] per scene (layout in oracle/ref_kat.cpp), colors float64[512, 5]
   (golden.json also holds the hashes of the scenes of tests/edge_scenes.py, named "edge:<name>")
 """
 import hashlib
@@ -67,7 +71,22 @@ int main(){ std::default_random_engine g; std::default_random_engine h; h.seed(0
         return json.loads(subprocess.check_output([os.path.join(td, "k")]).decode())
 
 
+KAT_CASES = (("scene.json", 400, 7), ("small_room.scene.json", 60, 8), ("small_mixed.scene.json", 40, 9))
+
+
+def function_kats():
+    out = {}
+    for name, n, seed in KAT_CASES:
+        rec, col = po.run_reference_kat(os.path.join(HERE, name), n, seed)
+        out["rec:" + name] = rec
+        out["colors"] = col
+        print("kat", name, rec.shape)
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
+
+
 def main():
+    if "--kat-only" in sys.argv:
+        return function_kats()
     if not po.have_reference():
         sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` first")
     out = []
@@ -98,6 +117,7 @@ def main():
 
     json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     json.dump(rng_kat(), open(os.path.join(HERE, "rng_kat.json"), "w"), indent=1)
+    function_kats()
 
 
 if __name__ == "__main__":

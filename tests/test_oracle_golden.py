@@ -104,3 +104,51 @@ def test_portable_math_accuracy():
     assert (np.abs(po.math_fn("pow", x, np.full_like(x, 1000.0))[m] - b[m]) / b[m]).max() < 1e-12
     assert np.isnan(po.math_fn("pow", np.array([-0.5]), np.array([0.5]))[0])
     assert po.math_fn("pow", np.array([-2.0, 0.0, 5.0]), np.array([3.0, 2.0, 0.0])).tolist() == [-8.0, 0.0, 1.0]
+
+
+# ---- function-level known answers (tests/golden/kat.npz, from the reference's own functions: oracle/ref_kat.cpp) ----
+KAT_SCENES = ["scene.json", "small_room.scene.json", "small_mixed.scene.json"]
+
+
+@pytest.mark.parametrize("name", KAT_SCENES)
+def test_function_level_known_answers(golden_dir, name):
+    """Solid::intersect of every object, get_intersection (point, normal, material), get_reflection_ray (with the RNG
+    state it leaves), get_refraction_ray entering and leaving, and whole paths (colour, ray count, RNG state after) on
+    seeded rays: the oracle reproduces every double of the reference's answers."""
+    rec = np.load(os.path.join(golden_dir, "kat.npz"))["rec:" + name]
+    sc = S.read_json_scene(os.path.join(golden_dir, name))
+    assert rec.shape[1] == 35 + 3 * len(sc.prims)
+    mine = po.kat(sc, rec[:, :7])
+    same = (rec.view(np.uint64) == mine.view(np.uint64)) | (np.isnan(rec) & np.isnan(mine))
+    assert same.all(), f"{name}: {int((~same).sum())} words differ, first at {np.argwhere(~same)[:4].tolist()}"
+    base = 7 + 3 * len(sc.prims)
+    assert np.isfinite(rec[:, base]).mean() > 0.9          # the rays hit something
+    assert (rec[:, base + 16] != 0).mean() > 0.5            # reflections were sampled (RNG state recorded)
+    assert (rec[:, base + 23:base + 26].sum(1) > 0).mean() > 0.1   # a share of the paths reaches an emitter
+
+
+def test_color_to_int_known_answers(golden_dir):
+    """Color::to_int (geometry.cpp:15-23) of 512 colours at three `max` values, through the oracle's expose() without bloom."""
+    col = np.load(os.path.join(golden_dir, "kat.npz"))["colors"]
+    for mx in np.unique(col[:, 3]):
+        sel = col[:, 3] == mx
+        img, _ = po.expose(col[sel, :3].reshape(1, -1, 3).copy(), 1.0 / mx, 0)
+        assert np.array_equal(img.reshape(-1).astype(np.int64), col[sel, 4].astype(np.int64))
+
+
+def test_survey_sample_ray(golden_dir):
+    """The reference's answers recorded while it was surveyed: the ray from the camera (0,0,40) through (-10,-14,-30)
+    meets the glass sphere objs[6] of scene.json at the point below, and the path of the centre ray from a fresh
+    default_random_engine is black after 3 rays and 6 draws (the next draw would be 101027544)."""
+    sc = S.read_json_scene(os.path.join(golden_dir, "scene.json"))
+    d = np.array([-10.0, -14.0, -30.0]) - np.array([0.0, 0.0, 40.0])
+    d /= np.sqrt((d * d).sum())
+    rec = po.kat(sc, np.array([[0.0, 0.0, 40.0, d[0], d[1], d[2], 1.0]]))[0]
+    want = [float.fromhex("-0x1.255d388b6340ep+3"), float.fromhex("-0x1.9ab5b58ff15adp+3"), float.fromhex("-0x1.82c645e7db62cp+4")]
+    got = rec[7 + 3 * 6: 7 + 3 * 6 + 3]
+    assert np.allclose(got, want, rtol=0, atol=1e-12), (got, want)     # the direction above is normalised here, not by Line()
+    centre = po.kat(sc, np.array([[0.0, 0.0, 40.0, 0.0, 0.0, -1.0, 1.0]]))[0]
+    base = 7 + 3 * len(sc.prims)
+    assert list(centre[base + 23:base + 26]) == [0.0, 0.0, 0.0] and centre[base + 26] == 3
+    g = int(centre[base + 27])
+    assert (g * 16807) % 2147483647 == 101027544

@@ -41,3 +41,15 @@ def test_oracle_equals_reference_binary_on_edge_scenes(name, header, objs):
     assert np.array_equal(ref["rgb"].view(np.uint64), o["rgb"].view(np.uint64))
     img, _ = po.expose(o["rgb"], sc.header["exposure"], 1)
     assert np.array_equal(img, ref["img"])
+
+
+@pytest.mark.parametrize("name,n,seed", [("scene.json", 300, 101), ("small_mixed.scene.json", 30, 102)])
+def test_oracle_functions_equal_reference_functions(golden_dir, name, n, seed):
+    """Fresh seeds through oracle/_ref/ref_kat: intersect / get_intersection / get_reflection_ray / get_refraction_ray /
+    add_to_path + trace of the reference against the oracle's restatement, every double."""
+    import os
+    path = os.path.join(golden_dir, name)
+    rec, col = po.run_reference_kat(path, n, seed)
+    mine = po.kat(S.read_json_scene(path), rec[:, :7])
+    same = (rec.view(np.uint64) == mine.view(np.uint64)) | (np.isnan(rec) & np.isnan(mine))
+    assert same.all(), f"{int((~same).sum())} words differ"
