@@ -31,7 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracer_amd import api, synth  # noqa: E402
-from raytracer_amd.dist import FramePipeline, sum_over_ranks  # noqa: E402
+from raytracer_amd.dist import FramePipeline, default_tile_rows, sum_over_ranks  # noqa: E402
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32, FMA = 2 FLOP
 
@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(synth.CONFIGS))
     ap.add_argument("--width", type=int, default=None, help="override the frame width (height follows 16:9)")
-    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--tile-rows", type=int, default=None,
+                    help="rows per tile of the cyclic partition (default: 8; with blur passes one band of rows per rank)")
+    ap.add_argument("--blurs", type=int, default=None, help="override num_blurs of the workload (the timing scenes have 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-frames", type=int, default=3, help="untimed frames with per-launch kernel timing")
     ap.add_argument("--no-walk", action="store_true", help="skip the second measurement (candidate solids from the grid walk)")
@@ -120,6 +122,10 @@ def main():
     H, W = sc.height, sc.width
     stream = torch.cuda.current_stream(device)
     exposure, blurs = float(sc.header["exposure"]), int(sc.header["num_blurs"])
+    if args.blurs is not None:
+        blurs = args.blurs
+    if args.tile_rows is None:
+        args.tile_rows = default_tile_rows(H, world, blurs)
     ev = []          # (start, end) HIP events around the render kernels of every timed frame, on the launch stream
     timed = [False]
 
@@ -136,7 +142,15 @@ def main():
 
     # one step = one frame as main() times it (main.cpp:305-315): render, expose (8-bit pack; the timing scenes have
     # num_blurs = 0), and the gather of the packed rows to rank 0
-    pipe = FramePipeline(H, W, blurs, args.tile_rows, rank, world, device, render_rows, expose)
+    # with blur passes and several ranks: over-exposure bits all-gathered, every rank blooms and packs its own rows
+    def expose_bits(src, rows, dst):
+        ren.expose_bits_device(src.data_ptr(), W, rows, exposure, dst.data_ptr(), stream=stream.cuda_stream)
+
+    def expose_rows(src, bits_all, pad_rows, dst):
+        ren.expose_rows_device(src.data_ptr(), bits_all.data_ptr(), W, H, args.tile_rows, rank, world, pad_rows, exposure, blurs,
+                               dst.data_ptr(), stream=stream.cuda_stream)
+
+    pipe = FramePipeline(H, W, blurs, args.tile_rows, rank, world, device, render_rows, expose, expose_bits, expose_rows)
 
     for _ in range(args.warmup):
         pipe.step()
@@ -222,7 +236,7 @@ def main():
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
                        "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",
-                       "step": "render + expose (num_blurs %d) + gather" % blurs},
+                       "step": "render + expose (num_blurs %d%s) + gather" % (blurs, ", bloom on every rank from all-gathered over-exposure bits" if pipe.halo else "")},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                          "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,

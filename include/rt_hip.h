@@ -188,6 +188,24 @@ int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids
 int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
                      int32_t* d_img, void* stream);
 
+/* expose() BEFORE the gather, for frames rendered by several ranks with num_blurs > 0 (with num_blurs == 0
+ * rt_expose_device on the rank's rows does).  The bloom's input B0 (main.cpp:198-205) is three bits per pixel: is the
+ * channel over-exposed.  Step 1, every rank: rt_expose_bits_device reduces its rendered rows to those bits.  Step 2,
+ * the caller: all-gather of the bits (1 byte per pixel; rank r's buffer at offset r*pad_rows*width).  Step 3, every
+ * rank: rt_expose_rows_device runs the blur passes on the 16-row blocks its own rows depend on (two more block rows of
+ * halo either side per pass), adds the bloom to its rows and packs them.  Same arithmetic per pixel as
+ * rt_expose_device on the whole frame: the packed rows equal the frame's rows bit for bit.  Asynchronous on `stream`.
+ *   d_rgb      : double[rows*width*3], the rank's rows as rt_render_rows_device packs them
+ *   d_bits     : uint8[rows*width], bit k set iff channel k of the pixel is over-exposed (rgb[k]*exposure > 1)
+ *   d_bits_all : uint8[world*pad_rows*width], every rank's bits; pad_rows >= the largest row count of a rank
+ *   d_img      : int32[rows*width], the rank's rows of the packed frame
+ * Replaces expose() + blur(), main.cpp:186-242 (which run on the whole frame after the threads have joined). */
+int rt_expose_bits_device(rt_handle h, const double* d_rgb, int width, int rows, double exposure, uint8_t* d_bits,
+                          void* stream);
+int rt_expose_rows_device(rt_handle h, const double* d_rgb, const uint8_t* d_bits_all, int width, int height,
+                          int tile_rows, int rank, int world, int pad_rows, double exposure, int num_blurs,
+                          int32_t* d_img, void* stream);
+
 /* Convenience: the whole of main()'s timed section on this device -- render every pixel, expose() with the exposure
  * and num_blurs of the uploaded scene header -- with only the packed image copied to the HOST (4 bytes per pixel
  * instead of the 24 of the radiance array).

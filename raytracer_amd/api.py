@@ -27,6 +27,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
+           "rt_expose_bits_device", "rt_expose_rows_device",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
 
 
@@ -78,6 +79,11 @@ def load_library(path: str = LIB_PATH):
         f.argtypes = [C.c_void_p, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     l.rt_expose_device.restype = C.c_int
     l.rt_expose_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    l.rt_expose_bits_device.restype = C.c_int
+    l.rt_expose_bits_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    l.rt_expose_rows_device.restype = C.c_int
+    l.rt_expose_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     l.rt_render_image.restype = C.c_int
     l.rt_render_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     l.rt_last_timing.restype = C.c_int
@@ -179,6 +185,19 @@ class Renderer:
         """expose() on the device (bloom + 8-bit pack): double[height*width*3] -> int32[height*width], asynchronous."""
         self._check(self.lib.rt_expose_device(self.h, C.c_void_p(d_rgb_ptr), int(width), int(height), float(exposure),
                                               int(num_blurs), C.c_void_p(d_img_ptr), C.c_void_p(stream) if stream else None))
+
+    def expose_bits_device(self, d_rgb_ptr, width, rows, exposure, d_bits_ptr, stream=None):
+        """Step 1 of expose() before the gather: the rank's rows -> one byte per pixel (bit k: channel k over-exposed)."""
+        self._check(self.lib.rt_expose_bits_device(self.h, C.c_void_p(d_rgb_ptr), int(width), int(rows), float(exposure),
+                                                   C.c_void_p(d_bits_ptr), C.c_void_p(stream) if stream else None))
+
+    def expose_rows_device(self, d_rgb_ptr, d_bits_all_ptr, width, height, tile_rows, rank, world, pad_rows, exposure, num_blurs,
+                           d_img_ptr, stream=None):
+        """Step 3: bloom (with halo block rows, from every rank's gathered bits) + 8-bit pack of the rank's own rows."""
+        self._check(self.lib.rt_expose_rows_device(self.h, C.c_void_p(d_rgb_ptr), C.c_void_p(d_bits_all_ptr) if d_bits_all_ptr else None,
+                                                   int(width), int(height), int(tile_rows), int(rank), int(world), int(pad_rows),
+                                                   float(exposure), int(num_blurs), C.c_void_p(d_img_ptr),
+                                                   C.c_void_p(stream) if stream else None))
 
     def finish(self):
         rays = C.c_uint64(0)

@@ -1169,10 +1169,18 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
         heavy = c > HEAVY_BITS;
     }
     if (live && !heavy) {
+        // the list's entries are requested two ahead: the first two before the always-tested solids, whose tests then
+        // cover the loads' latency (each entry would otherwise cost a trip to memory in the middle of the scan):
+        // C3 frame -0.2 ms
+        uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
+        if (n > 0u) cur = cl[0];
+        if (n > 1u) nxt = cl[cstride];
         narrow_always(alw, w.kp.n_always, o, d, h);
         ncand_total += (unsigned)w.kp.n_always;
         for (unsigned e = 0; e < n; e++) {
-            const uint2 ent = cl[e * cstride];
+            const uint2 ent = cur;
+            cur = nxt;
+            if (e + 2u < n) nxt = cl[(e + 2u) * cstride];
             unsigned m = ent.y;
             ncand_total += (unsigned)__popc(m);
             while (m) {
@@ -1310,11 +1318,15 @@ __global__ void expose_mask_kernel(const double* rgb, double* cur, size_t n3, do
 }
 
 // one pass of main.cpp:207-223 for one channel (blockIdx.z) of a 16x16 tile of pixels
+// block_rows: null = every 16-row block of the frame (blockIdx.y is the block row); else the list of block rows to
+// compute (a rank that blooms only what its own rows need, rt_expose_rows_device)
 __global__ __launch_bounds__(BLOOM_T * BLOOM_T) void bloom_kernel(const double* __restrict__ src, double* __restrict__ dst,
-                                                                  int W, int H, const double* __restrict__ kern) {
+                                                                  int W, int H, const double* __restrict__ kern,
+                                                                  const int* __restrict__ block_rows) {
     __shared__ double tile[BLOOM_TILE][BLOOM_TILE + 1];
     const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * BLOOM_T - BLOOM_R, y0 = blockIdx.y * BLOOM_T - BLOOM_R;
+    const int by = block_rows ? block_rows[blockIdx.y] : (int)blockIdx.y;
+    const int x0 = blockIdx.x * BLOOM_T - BLOOM_R, y0 = by * BLOOM_T - BLOOM_R;
     bool lit = false;
     for (int i = threadIdx.x; i < BLOOM_TILE * BLOOM_TILE; i += BLOOM_T * BLOOM_T) {
         const int ty = i / BLOOM_TILE, tx = i - ty * BLOOM_TILE;
@@ -1335,8 +1347,64 @@ __global__ __launch_bounds__(BLOOM_T * BLOOM_T) void bloom_kernel(const double* 
             for (int kx = 0; kx < BLOOM_K; kx++) c = c + tile[ly + ky][lx + kx] * krow[kx];
         }
     }
-    const int x = blockIdx.x * BLOOM_T + lx, y = blockIdx.y * BLOOM_T + ly;
+    const int x = blockIdx.x * BLOOM_T + lx, y = by * BLOOM_T + ly;
     if (x < W && y < H) dst[((size_t)y * W + x) * 3 + ch] = c;
+}
+
+DEV int to_int_x86(double v);
+
+// ---- expose() before the gather: every rank blooms and packs the rows it rendered -----------------------------
+// B0 (main.cpp:198-205) is three bits per pixel.  Each rank reduces its rows to those bits (expose_bits_kernel), the
+// ranks all-gather them (1 byte per pixel), and each rank then runs the blur passes on the 16-row blocks its own rows
+// depend on: pass p of n needs pass p-1 within 20 rows, so the block set grows by two block rows per pass going
+// backwards from the rank's own blocks (the halo).  Buffers are indexed by FRAME position, so a tap outside the frame is
+// a tap outside the frame here too.  Every pixel goes through the same operations as in rt_expose_device.
+
+// global row of a rank's packed row lr (cyclic row tiles)
+DEV int tile_global_row(int lr, int tile_rows, int rank, int world) {
+    return ((lr / tile_rows) * world + rank) * tile_rows + lr % tile_rows;
+}
+
+__global__ void expose_bits_kernel(const double* rgb, unsigned char* bits, size_t n, double exposure) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned b = 0;
+        for (int k = 0; k < 3; k++) if (rgb[3 * i + k] * exposure > 1.0) b |= 1u << k;
+        bits[i] = (unsigned char)b;
+    }
+}
+
+// B0 of the listed block rows from the gathered bits: bits_all[r][lr][x] = rank r's packed row lr
+__global__ void expose_b0_blocks_kernel(const unsigned char* __restrict__ bits_all, double* __restrict__ b0, int W, int H,
+                                        int tile_rows, int world, int pad_rows, double exposure,
+                                        const int* __restrict__ block_rows) {
+    const int by = block_rows[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * BLOOM_T) return;
+    const int y = by * BLOOM_T + t / W, x = t % W;
+    if (y >= H) return;
+    const int tile = y / tile_rows, r = tile % world, lr = (tile / world) * tile_rows + y % tile_rows;
+    const unsigned b = bits_all[((size_t)r * pad_rows + lr) * W + x];
+    double* o = b0 + ((size_t)y * W + x) * 3;
+    for (int k = 0; k < 3; k++) o[k] = ((b >> k) & 1u) ? exposure : 0.0;
+}
+
+// expose_pack_kernel for a rank's packed rows; the bloom is read at the pixel's frame position
+__global__ void expose_pack_rows_kernel(const double* rgb, const double* bloom, int* img, int W, int rows, int tile_rows,
+                                        int rank, int world, double exposure) {
+    const double mx = 1.0 / exposure;
+    const size_t n = (size_t)rows * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lr = (int)(i / (size_t)W), x = (int)(i - (size_t)lr * W);
+        const size_t f = (size_t)tile_global_row(lr, tile_rows, rank, world) * W + x;
+        int v[3];
+        for (int k = 0; k < 3; k++) {
+            const double col = rgb[3 * i + k] + bloom[3 * f + k];
+            int q = to_int_x86(255.0 * col / mx);
+            if (q > 255) q = 255;
+            v[k] = q;
+        }
+        img[i] = (int)(((unsigned)v[0] << 16) + ((unsigned)v[1] << 8) + (unsigned)v[2]);
+    }
 }
 
 // (int)x as the reference's compiler converts it (cvttsd2si): truncation, 0x80000000 when out of range or NaN
@@ -1451,6 +1519,10 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_bloom[2] = {nullptr, nullptr}; size_t bloom_doubles = 0;   // rt_expose_device scratch
     double* d_bloom_kern = nullptr;
+    // rt_expose_rows_device: block-row lists of the blur passes for one (height, tile_rows, rank, world, num_blurs)
+    int* d_bloom_lists = nullptr;
+    std::vector<int> bloom_list_ofs;             // pass p's list = d_bloom_lists[ofs[p] .. ofs[p+1])  (p = 0: B0)
+    int bloom_list_key[5] = {-1, -1, -1, -1, -1};
     bool events_pending = false;
     int last_streams = 0;
     rt_timing timing{};
@@ -1775,7 +1847,7 @@ void rt_destroy(rt_handle h) {
     hipSetDevice(h->device);
     free_scene(h);
     free_pipeline(h);
-    hipFree(h->d_bloom[0]); hipFree(h->d_bloom[1]); hipFree(h->d_bloom_kern);
+    hipFree(h->d_bloom[0]); hipFree(h->d_bloom[1]); hipFree(h->d_bloom_kern); hipFree(h->d_bloom_lists);
     hipFree(h->d_ctrl); hipFree(h->d_rgb); hipFree(h->d_hits); hipFree(h->d_stream_rays);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -2372,20 +2444,8 @@ int rt_render(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { retu
 
 int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids) { return render_host(h, 1, rgb, rays, hit_ids); }
 
-int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
-                     int32_t* d_img, void* stream) {
-    if (!h) return RT_ERR_ARG;
-    if (!d_rgb || !d_img || width < 1 || height < 1 || num_blurs < 0) return fail(h, RT_ERR_ARG, "rt_expose_device: bad argument");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)width * height;
-    unsigned grid = (unsigned)((n + 255) / 256);
-    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
-    if (num_blurs == 0) {
-        hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)nullptr, d_img, n, exposure);
-        HIP_TRY(h, hipGetLastError());
-        return RT_OK;
-    }
+// the Gaussian taps and the two frame-sized buffers the blur passes alternate between (n pixels)
+static int ensure_bloom(rt_handle h, size_t n) {
     if (!h->d_bloom_kern) {
         // the Gaussian of main.cpp:188-194, evaluated on the host with the C library's exp like the reference
         const double stddev = 3, denom = 2 * stddev * stddev;
@@ -2402,6 +2462,24 @@ int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, do
         for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&h->d_bloom[q], n * 3 * sizeof(double)));
         h->bloom_doubles = n * 3;
     }
+    return RT_OK;
+}
+
+int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
+                     int32_t* d_img, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!d_rgb || !d_img || width < 1 || height < 1 || num_blurs < 0) return fail(h, RT_ERR_ARG, "rt_expose_device: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)width * height;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
+    if (num_blurs == 0) {
+        hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)nullptr, d_img, n, exposure);
+        HIP_TRY(h, hipGetLastError());
+        return RT_OK;
+    }
+    { const int rc = ensure_bloom(h, n); if (rc != RT_OK) return rc; }
     unsigned g3 = (unsigned)((n * 3 + 255) / 256);
     if (g3 > (unsigned)h->cu_count * 32u) g3 = (unsigned)h->cu_count * 32u;
     hipLaunchKernelGGL(expose_mask_kernel, dim3(g3), dim3(256), 0, st, d_rgb, h->d_bloom[0], n * 3, exposure);
@@ -2409,10 +2487,83 @@ int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, do
     const dim3 bgrid((width + BLOOM_T - 1) / BLOOM_T, (height + BLOOM_T - 1) / BLOOM_T, 3);
     for (int b = 0; b < num_blurs; b++) {
         hipLaunchKernelGGL(bloom_kernel, bgrid, dim3(BLOOM_T * BLOOM_T), 0, st, (const double*)h->d_bloom[cur], h->d_bloom[cur ^ 1],
-                           width, height, (const double*)h->d_bloom_kern);
+                           width, height, (const double*)h->d_bloom_kern, (const int*)nullptr);
         cur ^= 1;
     }
     hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)h->d_bloom[cur], d_img, n, exposure);
+    HIP_TRY(h, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_expose_bits_device(rt_handle h, const double* d_rgb, int width, int rows, double exposure, uint8_t* d_bits, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!d_rgb || !d_bits || width < 1 || rows < 0) return fail(h, RT_ERR_ARG, "rt_expose_bits_device: bad argument");
+    if (rows == 0) return RT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)width * rows;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
+    hipLaunchKernelGGL(expose_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_rgb, d_bits, n, exposure);
+    HIP_TRY(h, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_expose_rows_device(rt_handle h, const double* d_rgb, const uint8_t* d_bits_all, int width, int height, int tile_rows,
+                          int rank, int world, int pad_rows, double exposure, int num_blurs, int32_t* d_img, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!d_rgb || !d_img || width < 1 || height < 1 || num_blurs < 0 || tile_rows < 1 || world < 1 || rank < 0 || rank >= world)
+        return fail(h, RT_ERR_ARG, "rt_expose_rows_device: bad argument");
+    const int rows = rt_rows_for_rank(height, tile_rows, rank, world);
+    if (rows == 0) return RT_OK;
+    // without a blur pass the bloom of a pixel is its own B0: nothing of another rank is needed
+    if (num_blurs == 0) return rt_expose_device(h, d_rgb, width, rows, exposure, 0, d_img, stream);
+    if (!d_bits_all) return fail(h, RT_ERR_ARG, "rt_expose_rows_device: the gathered bits are needed when num_blurs > 0");
+    for (int r = 0; r < world; r++)
+        if (rt_rows_for_rank(height, tile_rows, r, world) > pad_rows) return fail(h, RT_ERR_ARG, "rt_expose_rows_device: pad_rows is smaller than a rank's row count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)width * height;
+    { const int rc = ensure_bloom(h, n); if (rc != RT_OK) return rc; }
+    // block-row lists, last pass first: the blocks holding the rank's own rows, then two more block rows either side per
+    // earlier pass (a 16-row block's taps reach 20 rows); list 0 is where B0 is needed
+    const int nblk = (height + BLOOM_T - 1) / BLOOM_T;
+    const int key[5] = {height, tile_rows, rank, world, num_blurs};
+    if (memcmp(key, h->bloom_list_key, sizeof(key)) != 0) {
+        std::vector<char> need((size_t)nblk, 0);
+        for (int lr = 0; lr < rows; lr++) need[(size_t)(((lr / tile_rows) * world + rank) * tile_rows + lr % tile_rows) / BLOOM_T] = 1;
+        std::vector<std::vector<int>> lists((size_t)num_blurs + 1);
+        for (int p = num_blurs; p >= 0; p--) {
+            for (int b = 0; b < nblk; b++) if (need[b]) lists[p].push_back(b);
+            std::vector<char> grown((size_t)nblk, 0);
+            for (int b = 0; b < nblk; b++)
+                if (need[b]) for (int k = b - 2; k <= b + 2; k++) if (k >= 0 && k < nblk) grown[k] = 1;
+            need.swap(grown);
+        }
+        std::vector<int> flat;
+        h->bloom_list_ofs.assign(1, 0);
+        for (int p = 0; p <= num_blurs; p++) { flat.insert(flat.end(), lists[p].begin(), lists[p].end()); h->bloom_list_ofs.push_back((int)flat.size()); }
+        HIP_TRY(h, hipStreamSynchronize(st));            // an earlier call on this stream may still read the old lists
+        hipFree(h->d_bloom_lists); h->d_bloom_lists = nullptr;
+        h->bloom_list_key[0] = -1;
+        HIP_TRY(h, hipMalloc((void**)&h->d_bloom_lists, flat.size() * sizeof(int)));
+        HIP_TRY(h, hipMemcpy(h->d_bloom_lists, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+        memcpy(h->bloom_list_key, key, sizeof(key));
+    }
+    const std::vector<int>& ofs = h->bloom_list_ofs;
+    hipLaunchKernelGGL(expose_b0_blocks_kernel, dim3((unsigned)((width * BLOOM_T + 255) / 256), (unsigned)(ofs[1] - ofs[0])), dim3(256), 0, st,
+                       d_bits_all, h->d_bloom[0], width, height, tile_rows, world, pad_rows, exposure, (const int*)h->d_bloom_lists);
+    int cur = 0;
+    for (int p = 1; p <= num_blurs; p++) {
+        const dim3 bgrid((width + BLOOM_T - 1) / BLOOM_T, (unsigned)(ofs[p + 1] - ofs[p]), 3);
+        hipLaunchKernelGGL(bloom_kernel, bgrid, dim3(BLOOM_T * BLOOM_T), 0, st, (const double*)h->d_bloom[cur], h->d_bloom[cur ^ 1],
+                           width, height, (const double*)h->d_bloom_kern, (const int*)(h->d_bloom_lists + ofs[p]));
+        cur ^= 1;
+    }
+    const size_t nl = (size_t)rows * width;
+    unsigned grid = (unsigned)((nl + 255) / 256);
+    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
+    hipLaunchKernelGGL(expose_pack_rows_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)h->d_bloom[cur], d_img, width, rows,
+                       tile_rows, rank, world, exposure);
     HIP_TRY(h, hipGetLastError());
     return RT_OK;
 }

@@ -32,6 +32,16 @@ def max_rows(height: int, tile_rows: int, world: int) -> int:
     return max(len(rows_of_rank(height, tile_rows, r, world)) for r in range(world))
 
 
+def default_tile_rows(height: int, world: int, num_blurs: int) -> int:
+    """Tile height of the partition.  Without blur passes: 8-row tiles dealt out cyclically (load balance: rows through
+    dense geometry cost more rays).  With blur passes every rank blooms what its rows depend on, 20 rows either side per
+    pass: tiles that thin would make it bloom nearly the whole frame, so each rank gets ONE band of rows (4K, 3 passes,
+    8 ranks: 2.3 ms per rank against 10.9 ms with 8-row tiles)."""
+    if num_blurs > 0 and world > 1:
+        return (height + world - 1) // world
+    return 8
+
+
 class FrameGatherer:
     """Gathers per-rank packed row buffers into the full frame on rank 0.
 
@@ -48,10 +58,15 @@ class FrameGatherer:
         self.local = torch.empty((self.pad_rows, width * channels), dtype=dtype, device=device)
         if rank == 0:
             self.frame = torch.empty((height, width * channels), dtype=dtype, device=device)
-            self.index = [rows_of_rank(height, tile_rows, r, world).to(device) for r in range(world)]
-            self.recv = [torch.empty_like(self.local) for _ in range(world)] if world > 1 else None
+            # every rank's buffer lands in one tensor [world, pad_rows, W*c]; global row y is row src_row[y] of its
+            # flattened view, so the de-interleave is ONE index_select whatever the number of ranks
+            self.recv_all = torch.empty((world, self.pad_rows, width * channels), dtype=dtype, device=device) if world > 1 else None
+            self.recv = [self.recv_all[r] for r in range(world)] if world > 1 else None
+            y = torch.arange(height, dtype=torch.long)
+            tile = y // tile_rows
+            self.src_row = ((tile % world) * self.pad_rows + (tile // world) * tile_rows + y % tile_rows).to(device)
         else:
-            self.frame, self.index, self.recv = None, None, None
+            self.frame, self.recv_all, self.recv, self.src_row = None, None, None, None
         # a gloo group moves host memory: device buffers are staged through the host around the collective
         # (CPU tests, and rehearsals of the multi-rank flow on one GPU); RCCL ("nccl") takes them as they are
         self.stage = world > 1 and torch.device(device).type != "cpu" and dist.get_backend() == "gloo"
@@ -59,7 +74,8 @@ class FrameGatherer:
     def gather(self):
         """Collective.  Returns the frame tensor [height, width*channels] on rank 0, None elsewhere."""
         if self.world == 1:
-            self.frame.index_copy_(0, self.index[0], self.local[: len(self.index[0])])
+            # one rank owns every tile, in order: its buffer is the frame
+            self.frame.copy_(self.local[: self.h])
             return self.frame
         if self.stage:
             recv = [torch.empty(self.local.shape, dtype=self.dtype) for _ in range(self.world)] if self.rank == 0 else None
@@ -71,9 +87,7 @@ class FrameGatherer:
             dist.gather(self.local, self.recv if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
-        for r in range(self.world):
-            idx = self.index[r]
-            self.frame.index_copy_(0, idx, self.recv[r][: len(idx)])
+        torch.index_select(self.recv_all.view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
         return self.frame
 
 
@@ -81,26 +95,49 @@ class FramePipeline:
     """render -> expose -> gather, the sequence main() times (main.cpp:305-315), over the ranks of one node.
 
     num_blurs == 0 (every timing configuration): Color::to_int works pixel by pixel, so each rank packs the rows it
-    rendered and the gather moves 4 bytes per pixel instead of 24.  num_blurs > 0: the bloom reads 20 rows either
-    side of a pixel per pass, so the radiance rows are gathered and rank 0 exposes the whole frame.
+    rendered and the gather moves 4 bytes per pixel instead of 24.
+    num_blurs > 0: the bloom reads 20 rows either side of a pixel per pass.  Its input is three bits per pixel (is the
+    channel over-exposed, main.cpp:198-205), so with `expose_bits` / `expose_rows` given the ranks all-gather those
+    bits (1 byte per pixel), every rank blooms the block rows its own rows depend on and packs its rows, and the gather
+    again moves 4 bytes per pixel; the blur passes, the bulk of expose(), are shared out over the ranks.  Without the
+    two callables the radiance rows are gathered and rank 0 exposes the whole frame.
 
     render_rows(dst): fill dst[:my_rows] (float64 [rows, W*3]) with this rank's rows, in stream order.
     expose(src, rows, dst, num_blurs): pack src (float64 [rows, W*3]) into dst (int32 [rows, W]), in stream order.
-    On a GPU both are thin wrappers of rt_render_rows_device / rt_expose_device; the CPU tests pass oracle stand-ins.
+    expose_bits(src, rows, dst): dst (uint8 [rows, W]) = over-exposure bits of src (float64 [rows, W*3]).
+    expose_rows(src, bits_all, pad_rows, dst): bits_all (uint8 [world*pad_rows, W]) holds every rank's bits; pack this
+        rank's rows src (float64 [rows, W*3]) + bloom into dst (int32 [rows, W]).
+    On a GPU they are thin wrappers of rt_render_rows_device / rt_expose_device / rt_expose_bits_device /
+    rt_expose_rows_device; the CPU tests pass oracle stand-ins.
     """
 
-    def __init__(self, height, width, num_blurs, tile_rows, rank, world, device, render_rows, expose):
+    def __init__(self, height, width, num_blurs, tile_rows, rank, world, device, render_rows, expose,
+                 expose_bits=None, expose_rows=None):
         self.h, self.w, self.blurs = height, width, int(num_blurs)
         self.rank, self.world = rank, world
         self.render_rows, self.expose = render_rows, expose
+        self.expose_bits, self.expose_rows = expose_bits, expose_rows
         self.n_mine = len(rows_of_rank(height, tile_rows, rank, world))
-        if self.blurs == 0:
+        self.halo = self.blurs > 0 and world > 1 and expose_bits is not None and expose_rows is not None
+        if self.blurs == 0 or self.halo:
             self.rad = torch.empty((max_rows(height, tile_rows, world), width * 3), dtype=torch.float64, device=device)
             self.gat = FrameGatherer(height, width, 1, tile_rows, rank, world, device, dtype=torch.int32)
         else:
             self.gat = FrameGatherer(height, width, 3, tile_rows, rank, world, device, dtype=torch.float64)
             self.rad = self.gat.local
             self.img = torch.empty((height, width), dtype=torch.int32, device=device) if rank == 0 else None
+        if self.halo:
+            pad = self.gat.pad_rows
+            self.bits = torch.zeros((pad, width), dtype=torch.uint8, device=device)
+            self.bits_all = torch.empty((world * pad, width), dtype=torch.uint8, device=device)
+
+    def _all_gather_bits(self):
+        if dist.get_backend() == "gloo":                     # moves host memory (CPU tests, one-GPU rehearsals)
+            host = [torch.empty(self.bits.shape, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(host, self.bits.cpu())
+            self.bits_all.copy_(torch.cat(host, 0))
+        else:
+            dist.all_gather_into_tensor(self.bits_all, self.bits)
 
     def step(self):
         """One frame.  Collective.  Returns the packed frame int32[H, W] on rank 0, None elsewhere."""
@@ -108,6 +145,13 @@ class FramePipeline:
         if self.blurs == 0:
             if self.n_mine:
                 self.expose(self.rad, self.n_mine, self.gat.local, 0)
+            return self.gat.gather()
+        if self.halo:
+            if self.n_mine:
+                self.expose_bits(self.rad, self.n_mine, self.bits)
+            self._all_gather_bits()
+            if self.n_mine:
+                self.expose_rows(self.rad, self.bits_all, self.gat.pad_rows, self.gat.local)
             return self.gat.gather()
         frame = self.gat.gather()
         if self.rank != 0:

@@ -37,7 +37,7 @@ def _worker(rank, world, port, tile_rows, out_path):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, tile_rows, blurs, out_path):
+def _pipeline_worker(rank, world, port, tile_rows, blurs, use_halo, out_path):
     """render -> expose -> gather (FramePipeline) with the oracle standing in for both device calls."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
@@ -60,7 +60,26 @@ def _pipeline_worker(rank, world, port, tile_rows, blurs, out_path):
         img, _ = po.expose(src[:rows].numpy().reshape(rows, W, 3), exposure, nb, workers=2)
         dst[:rows] = torch.from_numpy(img)
 
-    pipe = FramePipeline(H, W, blurs, tile_rows, rank, world, torch.device("cpu"), render_rows, expose)
+    def expose_bits(src, rows, dst):
+        v = src[:rows].numpy().reshape(rows, W, 3) * exposure > 1.0
+        dst[:rows] = torch.from_numpy((v[..., 0] * 1 + v[..., 1] * 2 + v[..., 2] * 4).astype(np.uint8))
+
+    def expose_rows(src, bits_all, pad_rows, dst):
+        # stand-in for rt_expose_rows_device: a frame whose foreign rows merely reproduce their over-exposure bits
+        # (2/exposure where a bit is set) has the same B0, hence the same bloom, as the real frame
+        frame = np.zeros((H, W, 3))
+        ba = bits_all.numpy().reshape(world, pad_rows, W)
+        for r in range(world):
+            rr = rows_of_rank(H, tile_rows, r, world).numpy()
+            b = ba[r, : len(rr)]
+            frame[rr] = np.stack([(b >> k) & 1 for k in range(3)], -1) * (2.0 / exposure)
+        frame[mine] = src[: len(mine)].numpy().reshape(len(mine), W, 3)
+        img, _ = po.expose(frame, exposure, blurs, workers=2)
+        dst[: len(mine)] = torch.from_numpy(img[mine])
+
+    halo = dict(expose_bits=expose_bits, expose_rows=expose_rows) if use_halo else {}
+    pipe = FramePipeline(H, W, blurs, tile_rows, rank, world, torch.device("cpu"), render_rows, expose, **halo)
+    assert pipe.halo == (use_halo and blurs > 0)
     got = pipe.step()
     got = pipe.step()                                  # buffers are reused frame after frame
     if rank == 0:
@@ -71,13 +90,13 @@ def _pipeline_worker(rank, world, port, tile_rows, blurs, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,blurs", [(8, 0), (5, 0), (8, 1)])
-def test_two_rank_render_expose_gather(tmp_path, tile_rows, blurs):
-    """Packed 8-bit rows gathered (num_blurs = 0) and radiance rows gathered + rank-0 bloom (num_blurs > 0) both
-    give the single-process frame."""
+@pytest.mark.parametrize("tile_rows,blurs,halo", [(8, 0, False), (5, 0, False), (8, 1, False), (8, 1, True), (5, 2, True)])
+def test_two_rank_render_expose_gather(tmp_path, tile_rows, blurs, halo):
+    """Packed 8-bit rows gathered (num_blurs = 0), radiance rows gathered + rank-0 bloom, and over-exposure bits
+    all-gathered + every rank blooming its own rows (num_blurs > 0) all give the single-process frame."""
     out = str(tmp_path / "res.txt")
-    port = 31500 + (os.getpid() % 2000) + tile_rows + 16 * blurs
-    mp.spawn(_pipeline_worker, args=(2, port, tile_rows, blurs, out), nprocs=2, join=True)
+    port = 31500 + (os.getpid() % 2000) + tile_rows + 16 * blurs + 64 * int(halo)
+    mp.spawn(_pipeline_worker, args=(2, port, tile_rows, blurs, halo, out), nprocs=2, join=True)
     assert open(out).read() == "1"
 
 

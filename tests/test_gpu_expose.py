@@ -64,6 +64,59 @@ def test_expose_rows_before_gather(renderer):
     assert np.array_equal(part, whole[rows])
 
 
+def _expose_by_ranks(renderer, rgb, exposure, blurs, tile_rows, world):
+    """The frame exposed rank by rank as FramePipeline's halo mode does it on `world` GPUs: bits of every rank's rows,
+    concatenated as the all-gather delivers them, then rt_expose_rows_device per rank; rows put back in place."""
+    from raytracer_amd.dist import max_rows, rows_of_rank
+    H, W, _ = rgb.shape
+    st = torch.cuda.current_stream().cuda_stream
+    pad = max_rows(H, tile_rows, world)
+    rows = [rows_of_rank(H, tile_rows, r, world).numpy() for r in range(world)]
+    local = [torch.from_numpy(np.ascontiguousarray(rgb[rr])).to("cuda:0") if len(rr) else torch.zeros((1, W, 3), dtype=torch.float64, device="cuda:0")
+             for rr in rows]
+    bits_all = torch.full((world, pad, W), 0xff, dtype=torch.uint8, device="cuda:0")     # padding rows hold junk
+    for r in range(world):
+        bits = torch.empty((max(1, len(rows[r])), W), dtype=torch.uint8, device="cuda:0")
+        renderer.expose_bits_device(local[r].data_ptr(), W, len(rows[r]), exposure, bits.data_ptr(), st)
+        bits_all[r, : len(rows[r])] = bits[: len(rows[r])]
+    out = np.full((H, W), -7, dtype=np.int32)
+    for r in range(world):
+        img = torch.full((max(1, len(rows[r])), W), -7, dtype=torch.int32, device="cuda:0")
+        renderer.expose_rows_device(local[r].data_ptr(), bits_all.data_ptr(), W, H, tile_rows, r, world, pad, exposure, blurs,
+                                    img.data_ptr(), st)
+        torch.cuda.synchronize()
+        out[rows[r]] = img.cpu().numpy()[: len(rows[r])]
+    return out
+
+
+@pytest.mark.parametrize("shape,tile_rows,world,blurs", [((130, 70), 8, 2, 3), ((130, 70), 8, 8, 2), ((97, 33), 5, 3, 1),
+                                                         ((64, 40), 1, 4, 2), ((40, 50), 8, 8, 1), ((200, 48), 25, 8, 3),
+                                                         ((33, 47), 8, 2, 0)])
+def test_expose_by_ranks_with_halo_equals_whole_frame(renderer, shape, tile_rows, world, blurs):
+    """expose() before the gather: every rank blooms the block rows its own rows depend on, from all ranks'
+    over-exposure bits, and packs its rows.  Against the oracle's expose of the whole frame, every pixel equal;
+    ragged frames, ranks without rows (40 rows in tiles of 8 over 8 ranks), one-row tiles, band partitions."""
+    H, W = shape
+    rng = np.random.default_rng(H * 131 + W + world)
+    exposure = 0.9
+    rgb = rng.uniform(0, 1.15 / exposure, (H, W, 3))            # about an eighth of the channels saturate
+    rgb[H // 3, W // 2] = [np.nan, np.inf, -1.0]
+    want, _ = po.expose(rgb, exposure, blurs)
+    got = _expose_by_ranks(renderer, rgb, exposure, blurs, tile_rows, world)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} packed pixels differ"
+    assert np.array_equal(got, _expose_gpu(renderer, rgb, exposure, blurs))
+
+
+def test_expose_by_ranks_real_frame(renderer, golden_dir):
+    """scene.json (3 blur passes, 41.6 % of the pixels saturated) split over 4 ranks in 8-row tiles."""
+    sc = S.read_json_scene(os.path.join(golden_dir, "scene.json"))
+    renderer.upload(sc)
+    rgb = renderer.render()["rgb"]
+    want, _ = po.expose(rgb, sc.header["exposure"], 3)
+    got = _expose_by_ranks(renderer, rgb, sc.header["exposure"], 3, 8, 4)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} packed pixels differ"
+
+
 def test_render_image_equals_render_then_expose(renderer, golden_dir):
     """rt_render_image (render + device expose, packed frame to the host) against the two-step path, bloom included."""
     sc = S.read_json_scene(os.path.join(golden_dir, "small_room.scene.json"))
