@@ -92,6 +92,7 @@ def main():
                     help="rows per tile of the cyclic partition (default: 8; with blur passes one band of rows per rank)")
     ap.add_argument("--blurs", type=int, default=None, help="override num_blurs of the workload (the timing scenes have 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish a frame's gather before rendering the next")
     ap.add_argument("--roofline-frames", type=int, default=3, help="untimed frames with per-launch kernel timing")
     ap.add_argument("--no-walk", action="store_true", help="skip the second measurement (candidate solids from the grid walk)")
     args = ap.parse_args()
@@ -150,11 +151,15 @@ def main():
         ren.expose_rows_device(src.data_ptr(), bits_all.data_ptr(), W, H, args.tile_rows, rank, world, pad_rows, exposure, blurs,
                                dst.data_ptr(), stream=stream.cuda_stream)
 
-    pipe = FramePipeline(H, W, blurs, args.tile_rows, rank, world, device, render_rows, expose, expose_bits, expose_rows)
+    # Several ranks: a frame's gather (RCCL's own stream) runs while the next frame is rendered; the frames of the timed
+    # region are all gathered and put in row order inside it (flush).  --no-pipeline: gather, then the next render.
+    pipe = FramePipeline(H, W, blurs, args.tile_rows, rank, world, device, render_rows, expose, expose_bits, expose_rows,
+                         pipelined=world > 1 and not args.no_pipeline)
 
     for _ in range(args.warmup):
         pipe.step()
         ren.finish()
+    pipe.flush()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -162,7 +167,8 @@ def main():
     timed[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        frame = pipe.step()
+        pipe.step()
+    pipe.flush()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -179,6 +185,7 @@ def main():
     broad, serial = [], []
     for _ in range(args.roofline_frames):
         pipe.step()
+        pipe.flush()
         ren.finish()
         tm = ren.timing()
         broad.append(tm["broad_ms"] if tm["broad_ms"] > 0 else tm["kernel_ms"])
@@ -205,6 +212,7 @@ def main():
         for _ in range(max(1, args.warmup)):
             pipe.step()
             ren.finish()
+        pipe.flush()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -212,6 +220,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             pipe.step()
+        pipe.flush()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -236,7 +245,8 @@ def main():
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
                        "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",
-                       "step": "render + expose (num_blurs %d%s) + gather" % (blurs, ", bloom on every rank from all-gathered over-exposure bits" if pipe.halo else "")},
+                       "step": "render + expose (num_blurs %d%s) + gather" % (blurs, ", bloom on every rank from all-gathered over-exposure bits" if pipe.halo else "")
+                               + ("; a frame's gather overlaps the next frame's render" if pipe.pipelined else "")},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                          "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,

@@ -55,7 +55,10 @@ class FrameGatherer:
         self.device, self.dtype = device, dtype
         self.pad_rows = max_rows(height, tile_rows, world)
         self.my_rows = rows_of_rank(height, tile_rows, rank, world)
-        self.local = torch.empty((self.pad_rows, width * channels), dtype=dtype, device=device)
+        # two send buffers: `local` is the one to fill next (see gather_begin)
+        self._bufs = [torch.empty((self.pad_rows, width * channels), dtype=dtype, device=device) for _ in range(2)]
+        self._cur, self._work, self._sent = 0, None, None
+        self.local = self._bufs[0]
         if rank == 0:
             self.frame = torch.empty((height, width * channels), dtype=dtype, device=device)
             # every rank's buffer lands in one tensor [world, pad_rows, W*c]; global row y is row src_row[y] of its
@@ -73,21 +76,39 @@ class FrameGatherer:
 
     def gather(self):
         """Collective.  Returns the frame tensor [height, width*channels] on rank 0, None elsewhere."""
-        if self.world == 1:
-            # one rank owns every tile, in order: its buffer is the frame
-            self.frame.copy_(self.local[: self.h])
-            return self.frame
-        if self.stage:
-            recv = [torch.empty(self.local.shape, dtype=self.dtype) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(self.local.cpu(), recv, dst=0)
-            if self.rank == 0:
-                for r in range(self.world):
-                    self.recv[r].copy_(recv[r])
-        else:
-            dist.gather(self.local, self.recv if self.rank == 0 else None, dst=0)
+        self.gather_begin()
+        return self.gather_end()
+
+    # The gather in two halves, for callers that render the next frame while this one travels: gather_begin() starts the
+    # collective on the buffer `local` names and switches `local` to the other buffer; gather_end() waits for it (the
+    # current stream does, not the host, under RCCL) and puts the rows in frame order.  One gather in flight at a time.
+    def gather_begin(self):
+        buf = self.local
+        self._sent = buf
+        self._work = None
+        if self.world > 1:
+            if self.stage:
+                recv = [torch.empty(buf.shape, dtype=self.dtype) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(buf.cpu(), recv, dst=0)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.recv[r].copy_(recv[r])
+            else:
+                self._work = dist.gather(buf, self.recv if self.rank == 0 else None, dst=0, async_op=True)
+        self._cur ^= 1
+        self.local = self._bufs[self._cur]
+
+    def gather_end(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         if self.rank != 0:
             return None
-        torch.index_select(self.recv_all.view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
+        if self.world == 1:
+            # one rank owns every tile, in order: its buffer is the frame
+            self.frame.copy_(self._sent[: self.h])
+        else:
+            torch.index_select(self.recv_all.view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
         return self.frame
 
 
@@ -112,19 +133,23 @@ class FramePipeline:
     """
 
     def __init__(self, height, width, num_blurs, tile_rows, rank, world, device, render_rows, expose,
-                 expose_bits=None, expose_rows=None):
+                 expose_bits=None, expose_rows=None, pipelined=False):
         self.h, self.w, self.blurs = height, width, int(num_blurs)
         self.rank, self.world = rank, world
         self.render_rows, self.expose = render_rows, expose
         self.expose_bits, self.expose_rows = expose_bits, expose_rows
         self.n_mine = len(rows_of_rank(height, tile_rows, rank, world))
         self.halo = self.blurs > 0 and world > 1 and expose_bits is not None and expose_rows is not None
+        # pipelined: step() starts the gather of its frame and returns the PREVIOUS frame, whose gather ran while this
+        # one was rendered (flush() returns the last); only where packed rows are gathered
+        self.pipelined = bool(pipelined) and (self.blurs == 0 or self.halo)
+        self.pending = False
         if self.blurs == 0 or self.halo:
             self.rad = torch.empty((max_rows(height, tile_rows, world), width * 3), dtype=torch.float64, device=device)
             self.gat = FrameGatherer(height, width, 1, tile_rows, rank, world, device, dtype=torch.int32)
         else:
             self.gat = FrameGatherer(height, width, 3, tile_rows, rank, world, device, dtype=torch.float64)
-            self.rad = self.gat.local
+            self.rad = None                                  # rendered straight into the gatherer's send buffer
             self.img = torch.empty((height, width), dtype=torch.int32, device=device) if rank == 0 else None
         if self.halo:
             pad = self.gat.pad_rows
@@ -139,20 +164,36 @@ class FramePipeline:
         else:
             dist.all_gather_into_tensor(self.bits_all, self.bits)
 
+    def _gather_packed(self):
+        if not self.pipelined:
+            return self.gat.gather()
+        prev = self.gat.gather_end() if self.pending else None
+        self.gat.gather_begin()
+        self.pending = True
+        return prev
+
+    def flush(self):
+        """Pipelined mode: wait for the last frame's gather.  Returns it on rank 0 (None elsewhere, or nothing pending)."""
+        if not self.pending:
+            return None
+        self.pending = False
+        return self.gat.gather_end()
+
     def step(self):
-        """One frame.  Collective.  Returns the packed frame int32[H, W] on rank 0, None elsewhere."""
-        self.render_rows(self.rad)
+        """One frame.  Collective.  Returns the packed frame int32[H, W] on rank 0, None elsewhere (pipelined: the
+        previous step's frame, None on the first step)."""
+        self.render_rows(self.rad if self.rad is not None else self.gat.local)
         if self.blurs == 0:
             if self.n_mine:
                 self.expose(self.rad, self.n_mine, self.gat.local, 0)
-            return self.gat.gather()
+            return self._gather_packed()
         if self.halo:
             if self.n_mine:
                 self.expose_bits(self.rad, self.n_mine, self.bits)
             self._all_gather_bits()
             if self.n_mine:
                 self.expose_rows(self.rad, self.bits_all, self.gat.pad_rows, self.gat.local)
-            return self.gat.gather()
+            return self._gather_packed()
         frame = self.gat.gather()
         if self.rank != 0:
             return None

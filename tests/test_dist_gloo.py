@@ -37,7 +37,7 @@ def _worker(rank, world, port, tile_rows, out_path):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, tile_rows, blurs, use_halo, out_path):
+def _pipeline_worker(rank, world, port, tile_rows, blurs, use_halo, pipelined, out_path):
     """render -> expose -> gather (FramePipeline) with the oracle standing in for both device calls."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
@@ -78,10 +78,23 @@ def _pipeline_worker(rank, world, port, tile_rows, blurs, use_halo, out_path):
         dst[: len(mine)] = torch.from_numpy(img[mine])
 
     halo = dict(expose_bits=expose_bits, expose_rows=expose_rows) if use_halo else {}
-    pipe = FramePipeline(H, W, blurs, tile_rows, rank, world, torch.device("cpu"), render_rows, expose, **halo)
+    pipe = FramePipeline(H, W, blurs, tile_rows, rank, world, torch.device("cpu"), render_rows, expose, pipelined=pipelined, **halo)
     assert pipe.halo == (use_halo and blurs > 0)
-    got = pipe.step()
-    got = pipe.step()                                  # buffers are reused frame after frame
+    if pipelined:
+        # the gather of a frame runs while the next one is rendered: step() hands back the previous frame.  The second
+        # frame is rendered brighter so that a mixed-up buffer shows.
+        first = pipe.step()
+        assert first is None
+        want0, _ = po.expose(full["rgb"], exposure, blurs, workers=2)
+        full["rgb"] = full["rgb"] * 1.5
+        second = pipe.step()
+        if rank == 0:
+            assert np.array_equal(second.numpy().reshape(H, W), want0)
+        got = pipe.flush()
+        assert pipe.flush() is None
+    else:
+        got = pipe.step()
+        got = pipe.step()                              # buffers are reused frame after frame
     if rank == 0:
         want, _ = po.expose(full["rgb"], exposure, blurs, workers=2)
         ok = np.array_equal(got.numpy().reshape(H, W), want) and len(np.unique(want)) > 10
@@ -90,13 +103,16 @@ def _pipeline_worker(rank, world, port, tile_rows, blurs, use_halo, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,blurs,halo", [(8, 0, False), (5, 0, False), (8, 1, False), (8, 1, True), (5, 2, True)])
-def test_two_rank_render_expose_gather(tmp_path, tile_rows, blurs, halo):
+@pytest.mark.parametrize("tile_rows,blurs,halo,pipelined", [(8, 0, False, False), (5, 0, False, False), (8, 1, False, False),
+                                                           (8, 1, True, False), (5, 2, True, False), (8, 0, False, True),
+                                                           (5, 1, True, True)])
+def test_two_rank_render_expose_gather(tmp_path, tile_rows, blurs, halo, pipelined):
     """Packed 8-bit rows gathered (num_blurs = 0), radiance rows gathered + rank-0 bloom, and over-exposure bits
-    all-gathered + every rank blooming its own rows (num_blurs > 0) all give the single-process frame."""
+    all-gathered + every rank blooming its own rows (num_blurs > 0) all give the single-process frame; so does the
+    pipelined form, in which a frame's gather overlaps the next frame's render."""
     out = str(tmp_path / "res.txt")
-    port = 31500 + (os.getpid() % 2000) + tile_rows + 16 * blurs + 64 * int(halo)
-    mp.spawn(_pipeline_worker, args=(2, port, tile_rows, blurs, halo, out), nprocs=2, join=True)
+    port = 31500 + (os.getpid() % 2000) + tile_rows + 16 * blurs + 64 * int(halo) + 128 * int(pipelined)
+    mp.spawn(_pipeline_worker, args=(2, port, tile_rows, blurs, halo, pipelined, out), nprocs=2, join=True)
     assert open(out).read() == "1"
 
 
