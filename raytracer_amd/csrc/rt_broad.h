@@ -1,0 +1,57 @@
+// Broad phase: the conservative FP32 ray / bounding-sphere test and its per-ray constants.
+// A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
+#pragma once
+
+namespace {
+
+// ---- broad phase ---------------------------------------------------------------------------
+// Conservative float test of a ray against a bounding sphere (centre c, radius R), all
+// coordinates relative to the translation T and rounded to float.  With
+//     hb = d.(o - c) = d.o - d.c            oo = |o - c|^2 - R^2 = |o|^2 + (|c|^2 - R^2) - 2 o.c
+// the exact discriminant is hb^2 - oo.  The kernel evaluates, in 8 VALU instructions per record,
+//     hb' = od' - d'.c        (d' = d sqrt(1+delta), od' = d'.o: three fma)
+//     nq  = (R^2 - |c|^2) + 2 o.c            (three fma, the record carries R^2 - |c|^2)
+//     s   = hb'^2 + nq                        (one fma)          keep iff  s >= thr  (one compare)
+// with thr = |o|^2 - E0 - Eh^2 (1 + 1/delta).  If the float evaluation of hb is off by at most Eh
+// and that of oo by at most E0, then  hb^2 <= (|hb~| + Eh)^2 <= hb~^2 (1+delta) + Eh^2 (1+1/delta)
+// and  oo >= oo~ - E0, so a non-negative exact discriminant implies s >= thr: no primitive the
+// exact test could accept is ever dropped.  Bounds (S = |o| + cmax, u = 2^-24), with a factor 2 of
+// slack over the term-by-term count:  Eh = 14 u S,  E0 = 24 u S^2.
+// A kept sphere is still dropped if it lies wholly behind the origin: hb~ > Eh and oo~ > E0.
+constexpr float BROAD_DELTA = 1.9e-6f;         // used in thr; the applied scale 1.000001^2 - 1 is larger
+constexpr float BROAD_SCALE = 1.000001f;
+
+struct RayRec {
+    float4 a;   // -d' (xyz), od'
+    float4 b;   // 2 o (xyz), thr
+    float4 c;   // behind thresholds: hb' > c.x and nq < c.y ; zw unused
+};
+
+DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax) {
+    RayRec r;
+    const float ox = (float)(o.x - T[0]), oy = (float)(o.y - T[1]), oz = (float)(o.z - T[2]);
+    const float fx = (float)d.x * BROAD_SCALE, fy = (float)d.y * BROAD_SCALE, fz = (float)d.z * BROAD_SCALE;
+    const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
+    const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
+    const float S = __builtin_sqrtf((float)o2) * 1.0001f + cmax;
+    const float Eh = 14.0f * F32_U * S;
+    const float E0 = 24.0f * F32_U * S * S;
+    r.a = make_float4(-fx, -fy, -fz, (float)od);
+    const double thr = o2 - (double)E0 - (double)Eh * Eh * (1.0 + 1.0 / (double)BROAD_DELTA);
+    // rounded down, and strictly below: the pipeline keeps a record iff thr - s is negative
+    const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U) - 1e-30f;
+    r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);
+    const float bc = (float)(o2 - (double)E0) - __builtin_fabsf((float)o2) * (4.0f * F32_U);
+    r.c = make_float4(Eh * 1.00001f, bc, 0.0f, 0.0f);
+    return r;
+}
+
+// s and hb' of one record (cx, cy, cz, R^2 - |c|^2) for one ray; nq is returned for the behind test
+DEV float broad_s(const float4 rec, const float4 ra, const float4 rb, float& hb, float& nq) {
+    hb = __builtin_fmaf(ra.z, rec.z, __builtin_fmaf(ra.y, rec.y, __builtin_fmaf(ra.x, rec.x, ra.w)));
+    nq = __builtin_fmaf(rb.z, rec.z, __builtin_fmaf(rb.y, rec.y, __builtin_fmaf(rb.x, rec.x, rec.w)));
+    return __builtin_fmaf(hb, hb, nq);
+}
+DEV bool broad_behind(float hb, float nq, const float4 rc) { return hb > rc.x && nq < rc.y; }
+
+}  // namespace

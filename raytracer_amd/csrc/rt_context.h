@@ -1,0 +1,320 @@
+// Host side: the context behind rt_handle, grid construction, kernel launch helpers.
+// A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
+#pragma once
+
+constexpr int RT_MAX_SUB = 3;   // concurrent sub-pipelines (RT_OPT_OVERLAP); with the caller's stream they fit the 4 hardware queues of a process
+
+struct rt_context {
+    int device = 0;
+    int cu_count = 0;
+    std::string err;
+    bool have_scene = false;
+    // frame parameters
+    int width = 0, height = 0, spp = 0, depth = 0, num_threads = 1;
+    double scale = 0, lens = 0, focal = 0, exposure = 1;
+    double cam[3] = {0, 0, 40};
+    int num_blurs = 0;
+    unsigned frame_seed = 0;
+    int has_light = 0, light_draws = 0;
+    bool regular_paths = false;   // every path ends within 2*depth+1 segments (an emitter exists, no index-1 glass)
+    int n_prims = 0;
+    uint64_t n_spheres = 0, n_planes = 0, n_faces = 0, n_face_verts = 0;
+    // device scene
+    void* d_records = nullptr;
+    void* d_chunks = nullptr;
+    void* d_prims = nullptr;
+    void* d_verts = nullptr;
+    void* d_mats = nullptr;
+    void* d_always = nullptr; int n_always = 0, always_doubles = 0;
+    // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
+    uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
+    GridD grid{}; bool grid_ok = false; size_t grid_items = 0;
+    int nchunks = 0;
+    int max_chunk_records = 0;
+    int n_records_padded = 0;  // records incl. the NaN padding of every LDS window
+    float cmax = 0;
+    double T[3] = {0, 0, 0};
+    unsigned* d_ctrl = nullptr;
+    unsigned long long* d_stream_rays = nullptr; int stream_cap = 0;
+    // pipeline state (per-pixel mode): one set per concurrent sub-pipeline, sized for `slots` pixel slots and `verts`
+    // stack entries
+    struct PipeBufs {
+        size_t slots = 0; int verts = 0; int iters = 0;
+        int* si[2] = {nullptr, nullptr}; double2* sd[2] = {nullptr, nullptr}; double* stack = nullptr; double* acc = nullptr;
+        unsigned* queue[2] = {nullptr, nullptr};
+        unsigned* counts = nullptr;
+        float4* rec[2] = {nullptr, nullptr};
+        uint2* cand = nullptr; unsigned* cand_cnt = nullptr;
+    } pb[RT_MAX_SUB];
+    hipStream_t sub_stream[RT_MAX_SUB] = {};   // overlap mode: the sub-pipelines' streams
+    hipEvent_t fork_ev = nullptr, join_ev[RT_MAX_SUB] = {};
+    std::vector<hipEvent_t> broad_ev;   // pairs around every broad_kernel launch when timing_detail is on
+    int broad_ev_used = 0;
+    // scratch outputs of rt_render
+    double* d_rgb = nullptr; size_t d_rgb_bytes = 0;
+    int32_t* d_hits = nullptr; size_t d_hits_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_bloom[2] = {nullptr, nullptr}; size_t bloom_doubles = 0;   // rt_expose_device scratch
+    double* d_bloom_kern = nullptr;
+    // rt_expose_rows_device: block-row lists of the blur passes for one (height, tile_rows, rank, world, num_blurs)
+    int* d_bloom_lists = nullptr;
+    std::vector<int> bloom_list_ofs;             // pass p's list = d_bloom_lists[ofs[p] .. ofs[p+1])  (p = 0: B0)
+    int bloom_list_key[5] = {-1, -1, -1, -1, -1};
+    bool events_pending = false;
+    int last_streams = 0;
+    rt_timing timing{};
+    // options
+    int mode = RT_MODE_PIPELINE;
+    int timing_detail = 0;
+    int block = 256;           // single-kernel renderer: workgroup size
+    int broad_block = 512;     // broad_kernel workgroup size
+    int grid_mult = 0;         // workgroups per CU, 0 = ask the occupancy API
+    int chunk_records = 8192;  // LDS window in records (16 bytes each)
+    size_t max_slots = (size_t)1 << 25;
+    int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
+    double grid_density = 1.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY); 0.5 to 8 measured: flat optimum, 1 best on C4
+};
+
+namespace {
+
+int fail(rt_context* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(h, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_scene(rt_context* h) {
+    hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
+    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux);
+    h->d_cells = nullptr; h->d_item_rec = nullptr; h->d_item_aux = nullptr; h->grid_ok = false;
+    h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = h->d_always = nullptr;
+    h->have_scene = false;
+}
+
+void free_pipeline(rt_context* h) {
+    for (auto& b : h->pb) {
+        for (int q = 0; q < 2; q++) { hipFree(b.si[q]); hipFree(b.sd[q]); hipFree(b.queue[q]); hipFree(b.rec[q]); }
+        hipFree(b.stack); hipFree(b.counts); hipFree(b.acc); hipFree(b.cand); hipFree(b.cand_cnt);
+        b = rt_context::PipeBufs();
+    }
+}
+
+// smallest float >= x
+float round_up_f(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+// the broad-phase record of a bounding sphere (centre c relative to T, radius R): (c, R^2 - |c|^2) with the
+// radius inflated for the rounding of the centre to float; returns |c| + R for the scene-wide cmax
+double make_record(const double* c, double R, float* out) {
+    double c2 = 0, cn = 0;
+    for (int k = 0; k < 3; k++) {
+        out[k] = (float)c[k];
+        c2 += (double)out[k] * out[k];
+        cn += c[k] * c[k];
+    }
+    const double Rr = R * (1.0 + 1e-6) + 2.0 * sqrt(cn) * 5.9604645e-8 * 1.7320508;
+    out[3] = round_up_f(Rr * Rr - c2);
+    return sqrt(cn) + Rr;
+}
+
+
+// Uniform grid over the bounded solids that are not in the always table, for walk_kernel.  bc/br: bounding sphere of
+// every solid (radius < 0: unbounded), T: the translation of the float coordinates.  A solid is listed in every cell
+// that the box of its bounding sphere, grown by `pad`, overlaps.  Returns false when the scene cannot use the grid
+// (an unbounded solid outside the always table would have to be listed everywhere).
+struct GridHost {
+    GridD g;
+    size_t items = 0;                 // (solid, cell) pairs listed
+    std::vector<unsigned> cells;      // 8 per cell (GridD::cells)
+    std::vector<float> item_rec;      // 4 per further item
+    std::vector<unsigned> item_aux;   // 2 per further item
+};
+
+bool build_grid(int n_prims, const std::vector<PrimD>& pd, const std::vector<double>& bc, const std::vector<double>& br,
+                const std::vector<char>& always, const double* T, double density, GridHost& out) {
+    const double U = 5.9604645e-8;
+    std::vector<int> ids;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n_prims; i++) {
+        if (always[i]) continue;
+        if (br[i] < 0) return false;
+        ids.push_back(i);
+        for (int k = 0; k < 3; k++) {
+            const double c = bc[(size_t)i * 3 + k] - T[k];
+            if (c - br[i] < lo[k]) lo[k] = c - br[i];
+            if (c + br[i] > hi[k]) hi[k] = c + br[i];
+        }
+    }
+    GridD& g = out.g;
+    memset(&g, 0, sizeof(g));
+    if (ids.empty()) {                     // one empty cell: every walk ends at once with an empty list
+        for (int k = 0; k < 3; k++) { g.lo[k] = -1.0f; g.hi[k] = 1.0f; g.cell[k] = 2.0f; g.inv_cell[k] = 0.5f; g.n[k] = 1; }
+        g.pad = 1e-3f; g.far = 1e30f;
+        out.cells.assign(8, 0u);
+        out.item_rec.assign(4, 0.0f); out.item_aux.assign(2, 0u);
+        return true;
+    }
+    double reach = 0;
+    for (int k = 0; k < 3; k++) { reach = fmax(reach, fabs(lo[k])); reach = fmax(reach, fabs(hi[k])); }
+    if (!(reach < 1e15)) return false;
+    if (reach < 1e-6) reach = 1e-6;
+    // resolution: about `density` cells per listed solid, cells as cubic as the box allows
+    double ext[3], vol = 1, emax = 0;
+    for (int k = 0; k < 3; k++) { ext[k] = hi[k] - lo[k]; emax = fmax(emax, ext[k]); }
+    for (int k = 0; k < 3; k++) { if (ext[k] < 1e-3 * emax) { const double grow = 0.5 * (1e-3 * emax - ext[k]); lo[k] -= grow; hi[k] += grow; ext[k] = hi[k] - lo[k]; } vol *= ext[k]; }
+    const double per_len = cbrt(density * (double)ids.size() / vol);
+    size_t cells = 1;
+    double cell_min = 1e300;
+    for (int k = 0; k < 3; k++) {
+        int n = (int)ceil(ext[k] * per_len);
+        n = n < 1 ? 1 : (n > 256 ? 256 : n);
+        g.n[k] = n;
+        cells *= (size_t)n;
+        cell_min = fmin(cell_min, ext[k] / n);
+    }
+    // pad: what float rounding can move a cell boundary or a point of the ray, 128 u (|origin| + reach) with a wide
+    // margin (the walk's own count is about 11 u).  Origins up to `far` from T are walked; `far` is as large as a
+    // pad of 2 % of the smallest cell allows, at least 8 and at most 1024 times the grid's reach.
+    double far = 0.02 * cell_min / (128.0 * U) - reach;
+    far = fmin(fmax(far, 8.0 * reach), 1024.0 * reach);
+    const double pad = 128.0 * U * (far + reach);
+    for (int k = 0; k < 3; k++) { lo[k] -= 2.0 * pad; hi[k] += 2.0 * pad; }
+    // the device recomputes a boundary as fma((float)i, cell, lo): lists are built from the same float values, and the
+    // upper corner is the boundary of index n
+    for (int k = 0; k < 3; k++) {
+        g.lo[k] = (float)lo[k];
+        if ((double)g.lo[k] > lo[k]) g.lo[k] = nextafterf(g.lo[k], -INFINITY);
+        g.cell[k] = round_up_f((hi[k] - (double)g.lo[k]) / g.n[k]);
+        g.inv_cell[k] = 1.0f / g.cell[k];
+        g.hi[k] = fmaf((float)g.n[k], g.cell[k], g.lo[k]);
+    }
+    g.pad = round_up_f(pad); g.far = (float)far;
+    auto cell_range = [&](int k, double a, double b, int& c0, int& c1) {
+        c0 = (int)floor((a - (double)g.lo[k]) / (double)g.cell[k]);
+        c1 = (int)floor((b - (double)g.lo[k]) / (double)g.cell[k]);
+        if (c0 < 0) c0 = 0;
+        if (c1 >= g.n[k]) c1 = g.n[k] - 1;
+        if (c1 < c0) c1 = c0;
+    };
+    std::vector<unsigned> cnt(cells, 0u), more(cells, 0u);
+    out.cells.assign(cells * 8, 0u);
+    for (int pass = 0; pass < 2; pass++) {
+        for (size_t q = 0; q < ids.size(); q++) {
+            const int i = ids[q];
+            int a0[3], a1[3];
+            double cc[3];
+            for (int k = 0; k < 3; k++) {
+                cc[k] = bc[(size_t)i * 3 + k] - T[k];
+                cell_range(k, cc[k] - br[i] - pad, cc[k] + br[i] + pad, a0[k], a1[k]);
+            }
+            float r4[4] = {0, 0, 0, 0};
+            float r2 = -1.0f;
+            if (pass == 1) {
+                make_record(cc, br[i], r4);
+                if (pd[i].kind == RT_KIND_SPHERE) {      // lower bound of r^2 for the certain-hit test
+                    const double v = pd[i].radius * pd[i].radius * (1.0 - 1e-6);
+                    r2 = (float)v;
+                    if ((double)r2 > v) r2 = nextafterf(r2, -INFINITY);
+                    if (!(r2 >= 0.0f)) r2 = 0.0f;
+                }
+            }
+            for (int z = a0[2]; z <= a1[2]; z++) for (int y = a0[1]; y <= a1[1]; y++) for (int x = a0[0]; x <= a1[0]; x++) {
+                const size_t ci = ((size_t)z * g.n[1] + y) * g.n[0] + x;
+                if (pass == 0) { cnt[ci]++; continue; }
+                unsigned* cr = &out.cells[ci * 8];
+                const unsigned k = cr[6]++;
+                if (k == 0) {
+                    memcpy(cr, r4, 16);
+                    cr[4] = (unsigned)i; memcpy(&cr[5], &r2, 4); cr[7] = more[ci];
+                } else {
+                    const size_t at = (size_t)more[ci] + k - 1;
+                    memcpy(&out.item_rec[at * 4], r4, 16);
+                    out.item_aux[at * 2] = (unsigned)i; memcpy(&out.item_aux[at * 2 + 1], &r2, 4);
+                }
+            }
+        }
+        if (pass == 0) {
+            size_t extra = 0, total = 0;
+            for (size_t c = 0; c < cells; c++) { more[c] = (unsigned)extra; if (cnt[c] > 1) extra += cnt[c] - 1; total += cnt[c]; }
+            if (total > (1u << 28)) return false;
+            out.items = total;
+            out.item_rec.assign(extra * 4 + 4, 0.0f);
+            out.item_aux.assign(extra * 2 + 2, 0u);
+        }
+    }
+    return true;
+}
+
+void fill_kparams(rt_context* h, KParams& kp) {
+    memset(&kp, 0, sizeof(kp));
+    kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
+    kp.scale = h->scale; kp.lens = h->lens; kp.focal = h->focal; kp.frame_seed = h->frame_seed;
+    for (int k = 0; k < 3; k++) kp.cam[k] = h->cam[k];
+    kp.has_light = h->has_light; kp.light_draws = h->light_draws;
+    kp.tile_rows = 1; kp.rank = 0; kp.world = 1;
+    kp.nchunks = h->nchunks;
+    kp.n_prims = h->n_prims;
+    kp.max_verts = RT_MAXV;
+    kp.cmax = h->cmax;
+    for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
+    kp.records = (const float4*)h->d_records;
+    kp.chunks = (const ChunkDesc*)h->d_chunks;
+    kp.prims = (const PrimD*)h->d_prims;
+    kp.verts = (const FaceV*)h->d_verts;
+    kp.mats = (const MatD*)h->d_mats;
+    kp.always = (const double*)h->d_always; kp.n_always = h->n_always; kp.always_doubles = h->always_doubles;
+    kp.ctrl = h->d_ctrl;
+}
+
+template <int BLOCK>
+hipError_t launch_render(rt_context* h, const KParams& kp, hipStream_t st) {
+    auto kern = render_kernel<BLOCK>;
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = h->grid_mult;
+    if (per_cu <= 0) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+    }
+    unsigned grid = (unsigned)(h->cu_count * per_cu);
+    unsigned need = (kp.total_items + BLOCK - 1) / BLOCK;
+    if (need < grid) grid = need ? need : 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, kp);
+    return hipGetLastError();
+}
+
+template <int BLOCK>
+hipError_t launch_broad(rt_context* h, const WfParams& w, unsigned grid, hipStream_t st) {
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipLaunchKernelGGL(broad_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, st, w);
+    return hipGetLastError();
+}
+
+template <int BLOCK>
+hipError_t broad_grid(rt_context* h, unsigned* grid) {
+    auto kern = broad_kernel<BLOCK>;
+    size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = h->grid_mult;
+    if (per_cu <= 0) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+    }
+    *grid = (unsigned)(h->cu_count * per_cu);
+    return hipSuccess;
+}
+
+}  // namespace

@@ -1,0 +1,167 @@
+// Pipeline, part 2: closest hit among the candidates and one path segment per queued ray (shade_kernel).
+// A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
+#pragma once
+
+namespace {
+
+// Closest hit of the ray queued at `pos` (get_intersection, main.cpp:34-43): the always-tested solids (table `alw`, LDS)
+// and the ray's kept records through the reference's exact test.  Called by whole waves.
+//
+// A ray that keeps very many records (a NaN ray keeps every record, a ray with a distant origin has wide error bounds;
+// list overflow is the extreme case) would hold one lane busy with hundreds of exact tests while its wave, its workgroup
+// (barrier) and in the end the kernel wait: 1000 tests are 0.25 ms, more than a whole round of a small frame.  Such a
+// ray is tested against EVERY solid by its whole wave instead -- lane l takes solids l, l+64, ... -- and the 64 partial
+// results are merged with get_intersection's order-independent acceptance (consider_q).
+constexpr unsigned HEAVY_WORDS = 6, HEAVY_BITS = 48;   // shared out: lists of more than 6 mask words with more than 48 records
+
+DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
+    const int lane = threadIdx.x & 63;
+    Hit h;
+    h.q = __builtin_inf(); h.idx = -1;
+    h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+    const unsigned n = live ? w.cand_cnt[(size_t)(w.iter & 1) * w.slots + pos] : 0u;
+    const uint2* cl = w.cand + pos;
+    const size_t cstride = w.slots;
+    bool heavy = n > (unsigned)WF_CAND_CAP;     // WF_OVERFLOW, or a shared list's count that passed the capacity
+    if (!heavy && n > HEAVY_WORDS) {
+        unsigned c = 0;
+        for (unsigned e = 0; e < n; e++) c += (unsigned)__popc(cl[e * cstride].y);
+        heavy = c > HEAVY_BITS;
+    }
+    if (live && !heavy) {
+        // the list's entries are requested two ahead: the first two before the always-tested solids, whose tests then
+        // cover the loads' latency (each entry would otherwise cost a trip to memory in the middle of the scan):
+        // C3 frame -0.2 ms
+        uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
+        if (n > 0u) cur = cl[0];
+        if (n > 1u) nxt = cl[cstride];
+        narrow_always(alw, w.kp.n_always, o, d, h);
+        ncand_total += (unsigned)w.kp.n_always;
+        for (unsigned e = 0; e < n; e++) {
+            const uint2 ent = cur;
+            cur = nxt;
+            if (e + 2u < n) nxt = cl[(e + 2u) * cstride];
+            unsigned m = ent.y;
+            ncand_total += (unsigned)__popc(m);
+            while (m) {
+                const int k = __clz((int)m);
+                m &= ~(0x80000000u >> k);
+                const int idx = (int)ent.x * BROAD_GROUP + k;
+                // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
+                // included: indices past the list are never dereferenced
+                if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+            }
+        }
+    }
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {
+        const int src = __builtin_ctzll(hm);
+        hm &= hm - 1ull;
+        const d3 ob = dmk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+        const d3 db = dmk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+        Hit hl;
+        hl.q = __builtin_inf(); hl.idx = -1;
+        hl.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+        for (int i = lane; i < w.kp.n_prims; i += 64) narrow_one(i, ob, db, w.kp, hl);
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(hl.q, off, 64);
+            const int oi = __shfl_xor(hl.idx, off, 64);
+            const d3 op = dmk(__shfl_xor(hl.p.x, off, 64), __shfl_xor(hl.p.y, off, 64), __shfl_xor(hl.p.z, off, 64));
+            if (oi >= 0) consider_q(oq, op, oi, hl);
+        }
+        if (lane == src) {
+            h = hl;
+            ncand_total += (unsigned)w.kp.n_prims;
+            atomicAdd(&w.kp.ctrl[6], 1u);
+        }
+    }
+    return h;
+}
+
+// exact narrow phase + one segment of add_to_path per queued ray; survivors are packed into the next queue
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w) {
+    extern __shared__ double alw[];
+    const unsigned count = w.counts[w.iter];
+    if (count == 0) return;
+    for (int i = threadIdx.x; i < w.kp.always_doubles; i += SHADE_BLOCK) alw[i] = w.kp.always[i];
+    __syncthreads();
+#if SHADE_PROFILE
+    // wave-cycles per section (find_hit | segment | barriers | emit), summed over waves into ctrl[16..]
+    unsigned long long prof[5] = {0, 0, 0, 0, 0};
+    unsigned long long tick = __builtin_amdgcn_s_memtime();
+#define SHADE_TICK(k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); prof[k] += now - tick; tick = now; }
+#else
+#define SHADE_TICK(k)
+#endif
+    __shared__ unsigned wg_cnt[2][SHADE_BLOCK / 64], wg_base[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = w.iter & 1, qo = qi ^ 1;
+    unsigned nrays = 0;
+    unsigned long long ncand_total = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    // every lane of a workgroup runs the same number of trips so that the ballot below sees whole waves
+    const unsigned trips = (count + stride - 1) / stride;
+    for (unsigned t = 0; t < trips; t++) {
+        const unsigned pos = t * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = pos < count;
+        bool alive = false;
+        PathState s;
+        unsigned slot = 0;
+        SHADE_TICK(0);
+        // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
+        d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
+        if (live) {
+            const double2* sd = w.sd[qi] + pos;
+            const size_t n = w.slots;
+            const double2 p0 = sd[0], p1 = sd[n], p2 = sd[2 * n];
+            ro = dmk(p0.x, p0.y, p1.x);
+            rd = dmk(p1.y, p2.x, p2.y);
+        }
+        const Hit h = find_hit(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
+        SHADE_TICK(1);
+        if (live) {
+            slot = w.queue[qi][pos];
+            load_state(w, qi, pos, slot, ro, rd, s);
+            nrays++;
+            FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
+            alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
+        }
+        SHADE_TICK(2);
+        // pack the surviving rays into the next queue: rank within the wave's ballot, the waves' survivor counts
+        // meet in LDS (double-buffered by trip parity) and the workgroup takes its range with ONE atomic --
+        // an atomic per wave on the one counter costs more than a millisecond per frame
+        const unsigned long long m = __ballot(alive);
+        unsigned* cnt = wg_cnt[t & 1];
+        if (lane == 0) cnt[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int k = 0; k < SHADE_BLOCK / 64; k++) tot += cnt[k];
+            wg_base[t & 1] = tot ? atomicAdd(&w.counts[w.iter + 1], tot) : 0u;
+        }
+        __syncthreads();
+        SHADE_TICK(3);
+        unsigned base = wg_base[t & 1];
+        for (int k = 0; k < wv; k++) base += cnt[k];
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (alive) emit_ray(w, base + rank, slot, s, qo);
+        SHADE_TICK(4);
+    }
+#if SHADE_PROFILE
+    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)(w.kp.ctrl + 16 + 2 * k), prof[k]);
+#endif
+    // ray and candidate totals: wave sums through LDS, one atomic pair per workgroup
+    unsigned long long r = nrays, cn = ncand_total;
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off, 64); cn += __shfl_down(cn, off, 64); }
+    __shared__ unsigned long long wg_tot[2][SHADE_BLOCK / 64];
+    if (lane == 0) { wg_tot[0][wv] = r; wg_tot[1][wv] = cn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r = 0; cn = 0;
+        for (int k = 0; k < SHADE_BLOCK / 64; k++) { r += wg_tot[0][k]; cn += wg_tot[1][k]; }
+        if (r) atomicAdd((unsigned long long*)(w.kp.ctrl + 2), r);
+        if (cn) atomicAdd((unsigned long long*)(w.kp.ctrl + 4), cn);
+    }
+}
+
+}  // namespace

@@ -1,0 +1,74 @@
+// Device-side scene tables and kernel parameters.
+// A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------ device data
+constexpr double RT_EPS = 0.001;               // Sphere/Plane::intersect, geometry.cpp:102,135-136
+constexpr int RT_MAXV = 2 * RT_MAX_DEPTH + 2;  // bounce-stack entries per lane
+constexpr int BROAD_UNROLL = 4;
+constexpr int CAND_CAP = 48;                   // candidate list entries per lane before an early narrow phase
+constexpr unsigned ERR_REJECT_GUARD = 1u, ERR_STACK = 2u;
+constexpr int REJECT_GUARD_ITERS = 1 << 20;
+constexpr float F32_U = 5.9604645e-8f;         // 2^-24, unit roundoff of float
+
+struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to a multiple of 32
+
+// The exact phase reads these tables lane by lane at unrelated addresses (each lane its own solid or material), and
+// the vector L1 then handles one request per lane and instruction whatever its width.  The records are therefore
+// aligned and ordered so that what a test needs comes in few 16-byte loads (ld2 / ldi4 below).
+struct alignas(32) PrimD {   // 96 bytes, indexed by file order: the narrow phase's exact data
+    double a[3];             // sphere centre | plane point | face verts[0]
+    double radius;
+    int kind, mat0, mat1, voff;
+    int vcnt, pad0, pad1, pad2;
+    double n[3];             // plane / face unit normal
+    double pad3;
+};
+
+// One face vertex with the two quantities Face::intersect (geometry.cpp:162-166) derives from the vertex
+// list for every ray: e = v_i - v_i+1 and to_next = e.(v_i - v_i+2), computed once on the host with the
+// same double operations.
+struct alignas(32) FaceV { double v[3]; double e[3]; double to_next; double pad; };
+
+struct alignas(16) MatD {    // struct Material (geometry.hpp:18-29) in double, 144 bytes
+    unsigned is_light;
+    unsigned gloss_thr;      // glossy iff rng < gloss_thr  (= ceil(gloss * 2147483646), main.cpp:48)
+    double rindex;           // the three above: what a hit decides on, one 16-byte load
+    double sexp;
+    double ref[3];
+    double diff[3], spec[3];     // 48 bytes from offset 48
+    double rdiff[3], rspec[3];   // 48 bytes from offset 96
+};
+
+struct KParams {
+    int width, height, spp, depth;
+    double scale, lens, focal;
+    double cam[3];           // camera, main.cpp:16
+    unsigned frame_seed;
+    int has_light, light_draws;
+    int tile_rows, rank, world;
+    int stream_mode, n_streams;
+    unsigned total_items;
+    int nchunks;
+    int n_prims;
+    int max_verts;           // bounce-stack entries available per path (<= RT_MAXV)
+    float cmax;              // max |C - T| + R over finite bounding spheres
+    double T[3];             // translation applied before rounding coordinates to float
+    const float4* records;
+    const ChunkDesc* chunks;
+    const PrimD* prims;
+    const FaceV* verts;
+    const MatD* mats;
+    const double* always;    // solids every ray must test exactly (unbounded or very large bounding sphere): per solid
+                             // ALW_HEAD doubles (kind, file index, vertex count, -, point[3], radius, normal[3], -) and
+                             // 8 doubles per face vertex (FaceV); their broad-phase records are padding
+    int n_always, always_doubles;
+    double* rgb;
+    int* hit_ids;
+    unsigned long long* stream_rays;
+    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64), [6] rays whose candidate list overflowed
+};
+
+}  // namespace
