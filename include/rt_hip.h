@@ -233,6 +233,13 @@ int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* 
 int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* dirs, const double* centres,
                       const double* radii, int32_t* flags);
 
+/* Host-only self-test (no GPU call): the bounding sphere the library gives a face before the FP32 broad phase and the
+ * grid may cull it.  Face::intersect (geometry.cpp:160-168) accepts, per vertex, a half-plane bordered by the line through
+ * v_i perpendicular to edge i -- the polygon only for rectangles, a larger or unbounded region otherwise -- and the sphere
+ * must hold that whole region.  normal: the unit normal as the loader leaves it (readShape.cpp:95).
+ * Returns 1 and (centre[3], radius) when the region is bounded, 0 when the face is tested for every ray, < 0 on error. */
+int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius);
+
 #ifdef __cplusplus
 }
 #endif

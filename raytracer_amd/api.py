@@ -28,7 +28,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad")
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_face_bound")
 
 
 class RtError(RuntimeError):
@@ -94,8 +94,23 @@ def load_library(path: str = LIB_PATH):
     l.rt_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
     l.rt_selftest_broad.restype = C.c_int
     l.rt_selftest_broad.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+    l.rt_face_bound.restype = C.c_int
+    l.rt_face_bound.argtypes = [C.c_int, dp, dp, dp, dp]
     _lib = l
     return l
+
+
+def face_bound(verts, normal):
+    """Bounding sphere of the region Face::intersect accepts for this face: (centre[3], radius), or None when the region
+    is unbounded (the face is then tested for every ray).  Host arithmetic only."""
+    v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    n = np.ascontiguousarray(normal, dtype=np.float64)
+    c = np.zeros(3)
+    r = C.c_double(0.0)
+    rc = load_library().rt_face_bound(len(v), _dp(v), _dp(n), _dp(c), C.byref(r))
+    if rc < 0:
+        raise RtError(rc, "rt_face_bound: bad argument")
+    return (c, float(r.value)) if rc == 1 else None
 
 
 def rows_for_rank(height, tile_rows, rank, world):

@@ -127,6 +127,87 @@ double make_record(const double* c, double R, float* out) {
 }
 
 
+// Bounding sphere of the points Face::intersect can return (geometry.cpp:160-168).  The reference does NOT test the
+// polygon: a point p of the plane (verts[0], n) is accepted iff for every i the products
+//     to_p * to_next,   to_p = e_i.(v_i - p),   to_next = e_i.(v_i - v_i+2),   e_i = v_i - v_i+1
+// are not negative -- per vertex one half-plane whose border passes through v_i PERPENDICULAR to edge i, on the side
+// of v_i+2's projection onto that edge; a vertex whose to_next is zero constrains nothing.  The accepted region is the
+// intersection of those half-planes: the polygon itself for a rectangle, a larger convex region for any other shape
+// (an acute triangle: a larger triangle around it; a right triangle or a parallelogram: an unbounded wedge or strip).
+// The region is built by clipping a square of half-width 1e4 x (extent of the vertices) in the face's plane with every
+// half-plane, each moved outwards by a tolerance; constraints with a to_next that rounding could flip are left out
+// (both only enlarge the region).  Returns false (unbounded: the face is tested for every ray) when the clipped
+// region still touches the square, is empty, or the input is not finite; else centre and radius of a sphere around it.
+bool face_bound(const double* v, int nv, const double* n, double* centre, double* radius) {
+    if (nv < 1) return false;
+    for (int k = 0; k < 3 * nv; k++) if (!std::isfinite(v[k])) return false;
+    const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!std::isfinite(nl) || !(fabs(nl - 1.0) < 1e-6)) return false;
+    double cen[3] = {0, 0, 0};
+    for (int k = 0; k < nv; k++) for (int a = 0; a < 3; a++) cen[a] += v[3 * k + a] / nv;
+    double ext = 0;
+    for (int k = 0; k < nv; k++) {
+        double dd = 0;
+        for (int a = 0; a < 3; a++) dd += (v[3 * k + a] - cen[a]) * (v[3 * k + a] - cen[a]);
+        ext = fmax(ext, sqrt(dd));
+    }
+    if (!(ext > 1e-12) || !std::isfinite(ext)) return false;   // (a smaller face: products below could underflow)
+    // frame of the plane: origin = the vertex centroid dropped onto the plane through verts[0], axes u, w
+    double off = 0;
+    for (int a = 0; a < 3; a++) off += (cen[a] - v[a]) * n[a];
+    double org[3];
+    for (int a = 0; a < 3; a++) org[a] = cen[a] - off * n[a];
+    int least = 0;
+    for (int a = 1; a < 3; a++) if (fabs(n[a]) < fabs(n[least])) least = a;
+    double ax[3] = {0, 0, 0}; ax[least] = 1.0;
+    double u[3] = {n[1] * ax[2] - n[2] * ax[1], n[2] * ax[0] - n[0] * ax[2], n[0] * ax[1] - n[1] * ax[0]};
+    const double ul = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int a = 0; a < 3; a++) u[a] /= ul;
+    const double w[3] = {n[1] * u[2] - n[2] * u[1], n[2] * u[0] - n[0] * u[2], n[0] * u[1] - n[1] * u[0]};
+    const double L = 1e4 * (ext + fabs(off));
+    std::vector<double> poly = {-L, -L, L, -L, L, L, -L, L}, next;
+    for (int i = 0; i < nv; i++) {
+        const double* vi = v + 3 * i; const double* v1 = v + 3 * ((i + 1) % nv); const double* v2 = v + 3 * ((i + 2) % nv);
+        double e[3], to_next = 0, el = 0, wl = 0, k0 = 0, ku = 0, kw = 0;
+        for (int a = 0; a < 3; a++) {
+            e[a] = vi[a] - v1[a];
+            const double t = vi[a] - v2[a];
+            to_next += e[a] * t; el += e[a] * e[a]; wl += t * t;
+            k0 += e[a] * (vi[a] - org[a]); ku += e[a] * u[a]; kw += e[a] * w[a];
+        }
+        el = sqrt(el); wl = sqrt(wl);
+        if (!(fabs(to_next) > 1e-9 * el * wl) || el < 1e-100 || fabs(to_next) < 1e-200) continue;   // zero, or a sign rounding could decide
+                                                                     // (or to_p * to_next could underflow to 0): no constraint
+        if (!(fabs(ku) > 1e-12 * el || fabs(kw) > 1e-12 * el)) continue;   // edge perpendicular to the plane: all or nothing
+        const double sg = to_next > 0 ? 1.0 : -1.0, tol = 1e-9 * el * (ext + fabs(off));
+        // keep g(a, b) = sg (k0 - a ku - b kw) + tol >= 0
+        next.clear();
+        const size_t m = poly.size() / 2;
+        for (size_t j = 0; j < m; j++) {
+            const double a0 = poly[2 * j], b0 = poly[2 * j + 1], a1 = poly[2 * ((j + 1) % m)], b1 = poly[2 * ((j + 1) % m) + 1];
+            const double g0 = sg * (k0 - a0 * ku - b0 * kw) + tol, g1 = sg * (k0 - a1 * ku - b1 * kw) + tol;
+            if (g0 >= 0) { next.push_back(a0); next.push_back(b0); }
+            if ((g0 >= 0) != (g1 >= 0)) { const double t = g0 / (g0 - g1); next.push_back(a0 + t * (a1 - a0)); next.push_back(b0 + t * (b1 - b0)); }
+        }
+        poly.swap(next);
+        if (poly.empty()) return false;
+    }
+    const size_t m = poly.size() / 2;
+    double ca = 0, cb = 0;
+    for (size_t j = 0; j < m; j++) {
+        if (!(fabs(poly[2 * j]) < L * (1.0 - 1e-9) && fabs(poly[2 * j + 1]) < L * (1.0 - 1e-9))) return false;   // reaches the square (or NaN)
+        ca += poly[2 * j] / m; cb += poly[2 * j + 1] / m;
+    }
+    double R = 0;
+    for (size_t j = 0; j < m; j++) R = fmax(R, hypot(poly[2 * j] - ca, poly[2 * j + 1] - cb));
+    for (int a = 0; a < 3; a++) centre[a] = org[a] + ca * u[a] + cb * w[a];
+    // margin: the returned point is o + t d rounded (off the plane by rounding only), to_p is a rounded dot product
+    double big = 0;
+    for (int k = 0; k < 3 * nv; k++) big = fmax(big, fabs(v[k]));
+    *radius = R * (1.0 + 1e-6) + 1e-6 * ext + 1e-9 * big;
+    return std::isfinite(*radius);
+}
+
 // Uniform grid over the bounded solids that are not in the always table, for walk_kernel.  bc/br: bounding sphere of
 // every solid (radius < 0: unbounded), T: the translation of the float coordinates.  A solid is listed in every cell
 // that the box of its bounding sphere, grown by `pad`, overlaps.  Returns false when the scene cannot use the grid

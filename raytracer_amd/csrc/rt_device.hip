@@ -134,6 +134,11 @@ void rt_destroy(rt_handle h) {
 
 const char* rt_last_error(rt_handle h) { return h ? h->err.c_str() : "null handle"; }
 
+int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius) {
+    if (n_verts < 1 || !verts || !normal || !centre || !radius) return RT_ERR_ARG;
+    return face_bound(verts, n_verts, normal, centre, radius) ? 1 : 0;
+}
+
 int rt_rows_for_rank(int height, int tile_rows, int rank, int world) {
     if (height < 0 || tile_rows < 1 || world < 1 || rank < 0 || rank >= world) return RT_ERR_ARG;
     int rows = 0;
@@ -219,42 +224,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
             q.voff = off; q.vcnt = nv;
             h->n_faces++;
             h->n_face_verts += (uint64_t)nv;
-            // The reference accepts a point of the plane (verts[0], normal) iff, for every i, it is not on the
-            // other side of edge (v_i, v_i+1) than v_i+2.  For a planar convex polygon whose plane is the one
-            // the normal describes that region is the polygon, which lies inside the sphere around its
-            // vertices.  Anything else keeps an unbounded sphere (always a candidate).
-            const double* v = verts + (size_t)off * 3;
-            bool ok = nv >= 3;
-            double c[3] = {0, 0, 0};
-            for (int k = 0; k < nv && ok; k++) for (int a = 0; a < 3; a++) { if (!std::isfinite(v[3 * k + a])) ok = false; c[a] += v[3 * k + a] / nv; }
-            double R = 0, ext = 0;
-            for (int k = 0; k < nv && ok; k++) {
-                double dd = 0;
-                for (int a = 0; a < 3; a++) dd += (v[3 * k + a] - c[a]) * (v[3 * k + a] - c[a]);
-                if (sqrt(dd) > R) R = sqrt(dd);
-            }
-            ext = R > 0 ? R : 1.0;
-            for (int k = 0; k < nv && ok; k++) {          // planarity w.r.t. the given normal
-                double dist = 0;
-                for (int a = 0; a < 3; a++) dist += (v[3 * k + a] - v[a]) * q.n[a];
-                if (!(fabs(dist) <= 1e-9 * ext)) ok = false;
-            }
-            for (int k = 0; k < nv && ok; k++) {          // convexity: all vertices on one side of every edge
-                const double* a0 = v + 3 * k; const double* a1 = v + 3 * ((k + 1) % nv);
-                double e[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
-                double s[3] = {e[1] * q.n[2] - e[2] * q.n[1], e[2] * q.n[0] - e[0] * q.n[2], e[0] * q.n[1] - e[1] * q.n[0]};
-                int sign = 0;
-                for (int j = 0; j < nv && ok; j++) {
-                    const double* b = v + 3 * j;
-                    double t = (b[0] - a0[0]) * s[0] + (b[1] - a0[1]) * s[1] + (b[2] - a0[2]) * s[2];
-                    if (fabs(t) <= 1e-9 * ext * ext) continue;
-                    int sg = t > 0 ? 1 : -1;
-                    if (sign == 0) sign = sg; else if (sg != sign) ok = false;
-                }
-            }
-            if (ok) {
+            // the sphere around the region Face::intersect accepts, which is not the polygon (face_bound); a face whose
+            // region is unbounded keeps an unbounded sphere (always a candidate)
+            double c[3], R = 0;
+            if (nv >= 1 && face_bound(verts + (size_t)off * 3, nv, q.n, c, &R)) {
                 for (int k = 0; k < 3; k++) bc[(size_t)i * 3 + k] = c[k];
-                br[i] = R * (1.0 + 1e-6) + 1e-6 * ext;
+                br[i] = R;
                 bounded = true;
             }
         }

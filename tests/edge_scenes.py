@@ -1,6 +1,6 @@
 """Small scenes around the edges of the scene format and of the path logic
 (/root/reference/src/readShape.cpp:26-122, src/main.cpp:126-183): empty list, no emitter, every emitter kind,
-triangles and pentagons, a face that is neither planar nor convex, a solid larger than the room, glass of index 1,
+triangles and pentagons, faces whose accepted region is not their polygon, a face that is neither planar nor convex, a solid larger than the room, glass of index 1,
 depth 0 and the maximum depth, 1x1 and odd frame sizes.  Surfaces that can be met from behind are purely diffuse
 (a glossy one makes the reference's rejection loop spin, main.cpp:61-76).  Used by the GPU parity test, by the test
 that runs the compiled reference on them, and by tests/golden/make_golden.py."""
@@ -62,6 +62,16 @@ def _scenes():
     yield "depth_max", _header(3, depth=16, spp=1), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5, glass=1.5)]
     yield "one_pixel", _header(3, width=1, height=1, spp=5), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5)]
     yield "odd_frame_no_lens", _header(3, width=37, height=23, spp=3, lens=0.0), [FLOOR, CEIL_LIGHT, _sphere((0, -6, -10), 5)]
+    # Planar faces with exact normals whose accepted region (Face::intersect tests, per vertex, a half-plane bordered
+    # by the line through v_i perpendicular to edge i, geometry.cpp:162-166) reaches far outside the polygon: camera and
+    # bounce rays cross their planes outside the polygon and still hit.
+    rtri = _face([(-8, -8, -14), (4, -8, -14), (-8, 6, -14)], (0, 0, 1))                      # right triangle: unbounded region
+    yield "right_triangle_region", _header(4), [FLOOR, CEIL_LIGHT, rtri, _sphere((9, -8, -6), 3)]
+    atri = _face([(-6, -9, -10), (8, -9, -10), (1, 7, -10)], (0, 0, 1))                       # acute triangle: a larger triangle
+    para = _face([(-16, -2, -20), (-8, -2, -20), (-4, 6, -20), (-12, 6, -20)], (0, 0, 1))     # parallelogram
+    yield "acute_triangle_and_parallelogram", _header(5, width=64, height=36), [FLOOR, CEIL_LIGHT, atri, para, _sphere((12, -8, -4), 3)]
+    small = [_face([(x, y, -12), (x + 1.5, y, -12), (x + 0.75, y + 1.2, -12)], (0, 0, 1)) for x in (-12, -6, 0, 6, 12) for y in (-9, -4, 1)]
+    yield "small_acute_triangles", _header(2 + len(small), width=64, height=36, depth=2), [FLOOR, CEIL_LIGHT] + small
     many = [FLOOR, CEIL_LIGHT] + [_sphere((-18 + 1.2 * (i % 31), -10 + 1.2 * (i // 31), -12 - 0.1 * i), 0.5) for i in range(90)]
     yield "row_of_spheres_overflowing_lists", _header(len(many), width=64, height=36, depth=2, lens=0.0), many
 

@@ -160,3 +160,68 @@ def test_c_abi_entry_points_that_need_no_gpu():
         lib.rt_destroy(h)
     else:
         assert rc == -6 and not h.value
+
+
+# ---------------------------------------------------------------- bounding sphere of a face's accepted region
+def _face_accepts(verts, pts):
+    """Face::intersect's vertex loop (geometry.cpp:162-166) on points of the plane: to_p * to_next < 0 rejects."""
+    nv = len(verts)
+    ok = np.ones(len(pts), dtype=bool)
+    for i in range(nv):
+        e = verts[i] - verts[(i + 1) % nv]
+        to_next = e @ (verts[i] - verts[(i + 2) % nv])
+        to_p = (verts[i] - pts) @ e
+        ok &= ~(to_p * to_next < 0)
+    return ok
+
+
+FACES = {
+    # name: (verts, expected bounded?)
+    "rectangle": ([(-3, -2, -5), (4, -2, -5), (4, 1, -5), (-3, 1, -5)], True),
+    "tilted_square": ([(0, 0, 0), (1, 0, 1), (1, 1.5, 1), (0, 1.5, 0)], True),
+    "acute_triangle": ([(-6, -9, -10), (8, -9, -10), (1, 7, -10)], True),
+    "right_triangle": ([(-8, -8, -14), (4, -8, -14), (-8, 6, -14)], False),
+    "obtuse_triangle": ([(0, 0, 2), (10, 0, 2), (14, 3, 2)], None),
+    "parallelogram": ([(-10, -8, -16), (2, -8, -16), (8, 4, -16), (-4, 4, -16)], None),
+    "sheared_parallelogram": ([(0, 0, 1), (4, 0, 1), (24, 5, 1), (20, 5, 1)], None),
+    "pentagon": ([(12, -10, -8), (18, -6, -8), (16, 2, -8), (9, 3, -8), (7, -5, -8)], True),
+    "far_small_square": ([(1e6, 1e6, 3), (1e6 + 1, 1e6, 3), (1e6 + 1, 1e6 + 1, 3), (1e6, 1e6 + 1, 3)], True),
+    "two_vertices": ([(0, 0, 0), (1, 0, 0)], False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FACES))
+def test_face_bound_holds_every_accepted_point(name):
+    """No point the reference's Face::intersect accepts may lie outside the sphere the broad phase and the grid cull
+    with; shapes whose accepted region is unbounded must come back unbounded."""
+    verts, bounded = FACES[name]
+    v = np.array(verts, dtype=np.float64)
+    if len(v) >= 3:
+        n = np.cross(v[1] - v[0], v[2] - v[0])
+    else:
+        n = np.array([0.0, 0.0, 1.0])
+    n = n / np.linalg.norm(n)
+    b = api.face_bound(v, n)
+    if bounded is not None:
+        assert (b is not None) == bounded, f"{name}: bounded={b is not None}"
+    # points of the plane: dense around the face, and sparse out to 200 extents
+    rng = np.random.default_rng(5)
+    cen = v.mean(0)
+    ext = np.linalg.norm(v - cen, axis=1).max()
+    u = np.cross(n, [1.0, 0, 0] if abs(n[0]) < 0.9 else [0, 1.0, 0]); u /= np.linalg.norm(u)
+    w = np.cross(n, u)
+    ab = np.concatenate([rng.uniform(-4, 4, (200000, 2)), rng.uniform(-200, 200, (50000, 2))]) * ext
+    pts = cen + ab[:, :1] * u + ab[:, 1:] * w
+    pts = pts - ((pts - v[0]) @ n)[:, None] * n
+    acc = _face_accepts(v, pts)
+    assert acc.any()
+    if b is None:
+        assert bounded is not True
+        return
+    c, r = b
+    far = np.linalg.norm(pts[acc] - c, axis=1).max()
+    assert far <= r, f"{name}: accepted point {far} from the centre, radius {r}"
+    if name == "rectangle":
+        assert abs(r - 0.5 * np.hypot(7, 3)) < 1e-4
+    if name == "acute_triangle":     # the region is larger than the circle through the vertices allows
+        assert far > np.linalg.norm(v - cen, axis=1).max()
