@@ -188,6 +188,18 @@ int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids
 int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
                      int32_t* d_img, void* stream);
 
+/* rt_expose_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same kernels and the same
+ * packed frame bit for bit as rt_expose_device, but the blur passes' two frame-sized buffers and the Gaussian taps live in
+ * a fixed array inside the library (12 MiB + 16 KiB on every GPU the library is loaded on, held until the process ends)
+ * instead of buffers allocated on first use; the call makes no hipMalloc / hipFree.  Frames of more than
+ * RT_NOALLOC_MAX_PIXELS pixels are refused with RT_ERR_ARG (rt_last_error says so).  Every handle on a GPU shares that
+ * GPU's array: two calls that overlap in time on one GPU (different streams or threads) race; calls on one stream, or
+ * ordered by events, do not.  rt_create prepares the array for its device. */
+#define RT_NOALLOC_MAX_PIXELS 262144      /* 512 x 512; the reference's own scene.json is 400 x 400 */
+int rt_expose_device_noalloc(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
+                             int32_t* d_img, void* stream);
+
 /* expose() BEFORE the gather, for frames rendered by several ranks with num_blurs > 0 (with num_blurs == 0
  * rt_expose_device on the rank's rows does).  The bloom's input B0 (main.cpp:198-205) is three bits per pixel: is the
  * channel over-exposed.  Step 1, every rank: rt_expose_bits_device reduces its rendered rows to those bits.  Step 2,

@@ -22,12 +22,13 @@ RT_OK = 0
 # rt_set_option keys / values (include/rt_hip.h)
 OPT_MODE, OPT_TIMING_DETAIL, OPT_BLOCK, OPT_BROAD_BLOCK, OPT_WG_PER_CU, OPT_CHUNK_RECORDS, OPT_MAX_SLOTS, OPT_FUSE_NARROW, OPT_OVERLAP, OPT_ACCEL = range(10)
 MODE_PIPELINE, MODE_SINGLE_KERNEL = 0, 1
+NOALLOC_MAX_PIXELS = 262144         # RT_NOALLOC_MAX_PIXELS
 STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE", -4: "RT_ERR_SCENE",
           -5: "RT_ERR_GUARD", -6: "RT_ERR_NO_DEVICE"}
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
-           "rt_expose_bits_device", "rt_expose_rows_device",
+           "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_face_bound")
 
 
@@ -79,6 +80,8 @@ def load_library(path: str = LIB_PATH):
         f.argtypes = [C.c_void_p, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     l.rt_expose_device.restype = C.c_int
     l.rt_expose_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    l.rt_expose_device_noalloc.restype = C.c_int
+    l.rt_expose_device_noalloc.argtypes = l.rt_expose_device.argtypes
     l.rt_expose_bits_device.restype = C.c_int
     l.rt_expose_bits_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
     l.rt_expose_rows_device.restype = C.c_int
@@ -200,6 +203,11 @@ class Renderer:
         """expose() on the device (bloom + 8-bit pack): double[height*width*3] -> int32[height*width], asynchronous."""
         self._check(self.lib.rt_expose_device(self.h, C.c_void_p(d_rgb_ptr), int(width), int(height), float(exposure),
                                               int(num_blurs), C.c_void_p(d_img_ptr), C.c_void_p(stream) if stream else None))
+
+    def expose_device_noalloc(self, d_rgb_ptr, width, height, exposure, num_blurs, d_img_ptr, stream=None):
+        """expose_device on the library's fixed per-GPU buffer (no device allocation); frames up to NOALLOC_MAX_PIXELS."""
+        self._check(self.lib.rt_expose_device_noalloc(self.h, C.c_void_p(d_rgb_ptr), int(width), int(height), float(exposure),
+                                                      int(num_blurs), C.c_void_p(d_img_ptr), C.c_void_p(stream) if stream else None))
 
     def expose_bits_device(self, d_rgb_ptr, width, rows, exposure, d_bits_ptr, stream=None):
         """Step 1 of expose() before the gather: the rank's rows -> one byte per pixel (bit k: channel k over-exposed)."""

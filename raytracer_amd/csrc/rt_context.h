@@ -105,6 +105,16 @@ void free_pipeline(rt_context* h) {
     }
 }
 
+// the Gaussian of main.cpp:188-194, evaluated on the host with the C library's exp like the reference
+std::vector<double> bloom_taps() {
+    const double stddev = 3, denom = 2 * stddev * stddev;
+    std::vector<double> k((size_t)BLOOM_K * BLOOM_K);
+    for (int y = -BLOOM_R; y <= BLOOM_R; y++)
+        for (int x = -BLOOM_R; x <= BLOOM_R; x++)
+            k[(size_t)(y + BLOOM_R) * BLOOM_K + x + BLOOM_R] = exp(-(x * x + y * y) / denom) / denom / M_PI;
+    return k;
+}
+
 // smallest float >= x
 float round_up_f(double x) {
     float f = (float)x;

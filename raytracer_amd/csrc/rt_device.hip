@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,36 @@
 #include "rt_kernel_expose.h"   // expose kernels
 #include "rt_context.h"         // rt_context, host helpers
 
+// ---- device memory of rt_expose_device_noalloc: the Gaussian taps and the two buffers the blur passes alternate between,
+// for frames of up to RT_NOALLOC_MAX_PIXELS pixels, in a file-scope array that exists on every GPU from the moment the
+// library's code object is loaded there.  Layout: [0, NOALLOC_TAPS_BYTES) the 41 x 41 taps (written once per device by
+// noalloc_setup), then two buffers of RT_NOALLOC_MAX_PIXELS * 3 doubles.  In host code the array's name is only a
+// handle for hipGetSymbolAddress: the address each device holds it at is looked up once per device and kept in
+// g_scratch_ptr, and only that pointer is ever passed to kernels or copies.
+constexpr size_t NOALLOC_TAPS_BYTES = 16384;                                        // 1681 doubles, padded
+constexpr size_t NOALLOC_BUF_BYTES = (size_t)RT_NOALLOC_MAX_PIXELS * 3 * sizeof(double);
+constexpr size_t NOALLOC_BYTES = NOALLOC_TAPS_BYTES + 2 * NOALLOC_BUF_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES];     // per device: where that device holds `scratch`; null = not set up
+static std::mutex g_scratch_mutex;
+
+// once per device, with that device current (rt_create): look up the device's copy of the array and fill in the taps
+static int noalloc_setup(rt_context* h) {
+    if (h->device < 0 || h->device >= NOALLOC_MAX_DEVICES) return RT_OK;            // rt_expose_device_noalloc will refuse
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[h->device]) return RT_OK;
+    unsigned char* ptr = nullptr;
+    HIP_TRY(h, hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(h, RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    const std::vector<double> k = bloom_taps();
+    static_assert(BLOOM_K * BLOOM_K * sizeof(double) <= NOALLOC_TAPS_BYTES, "taps do not fit their part of the array");
+    HIP_TRY(h, hipMemcpy(ptr, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+    g_scratch_ptr[h->device] = ptr;
+    return RT_OK;
+}
+
 // ======================================================================= C ABI (include/rt_hip.h)
 extern "C" {
 
@@ -71,8 +102,13 @@ int rt_create(rt_handle* out, int device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
     h->cu_count = prop.multiProcessorCount;
     if (hipMalloc((void**)&h->d_ctrl, 256) != hipSuccess) { delete h; return RT_ERR_HIP; }
-    hipEventCreate(&h->ev0);
-    hipEventCreate(&h->ev1);
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || noalloc_setup(h) != RT_OK) {
+        if (h->ev0) hipEventDestroy(h->ev0);
+        if (h->ev1) hipEventDestroy(h->ev1);
+        hipFree(h->d_ctrl);
+        delete h;
+        return RT_ERR_HIP;
+    }
     // tuning knobs for experiments; rt_set_option is the API for the same values
     if (const char* e = getenv("RT_MODE")) rt_set_option(h, RT_OPT_MODE, strcmp(e, "mega") == 0 ? RT_MODE_SINGLE_KERNEL : RT_MODE_PIPELINE);
     if (const char* e = getenv("RT_BLOCK")) rt_set_option(h, RT_OPT_BLOCK, atoi(e));
@@ -697,12 +733,7 @@ int rt_render_streams(rt_handle h, double* rgb, uint64_t* rays, int32_t* hit_ids
 // the Gaussian taps and the two frame-sized buffers the blur passes alternate between (n pixels)
 static int ensure_bloom(rt_handle h, size_t n) {
     if (!h->d_bloom_kern) {
-        // the Gaussian of main.cpp:188-194, evaluated on the host with the C library's exp like the reference
-        const double stddev = 3, denom = 2 * stddev * stddev;
-        std::vector<double> k((size_t)BLOOM_K * BLOOM_K);
-        for (int y = -BLOOM_R; y <= BLOOM_R; y++)
-            for (int x = -BLOOM_R; x <= BLOOM_R; x++)
-                k[(size_t)(y + BLOOM_R) * BLOOM_K + x + BLOOM_R] = exp(-(x * x + y * y) / denom) / denom / M_PI;
+        const std::vector<double> k = bloom_taps();
         HIP_TRY(h, hipMalloc((void**)&h->d_bloom_kern, k.size() * sizeof(double)));
         HIP_TRY(h, hipMemcpy(h->d_bloom_kern, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
     }
@@ -741,6 +772,46 @@ int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, do
         cur ^= 1;
     }
     hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)h->d_bloom[cur], d_img, n, exposure);
+    HIP_TRY(h, hipGetLastError());
+    return RT_OK;
+}
+
+// rt_expose_device without a device allocation: the blur passes alternate between the two buffers of the file-scope
+// array (through the pointer noalloc_setup looked up for this device), the taps are the ones stored at its start.
+// Nothing of the array has to start at zero: expose_mask_kernel writes every element of B0 that the frame has and every
+// blur pass writes every element of its output before the next pass or the pack reads it.
+int rt_expose_device_noalloc(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
+                             int32_t* d_img, void* stream) {
+    if (!h) return RT_ERR_ARG;
+    if (!d_rgb || !d_img || width < 1 || height < 1 || num_blurs < 0) return fail(h, RT_ERR_ARG, "rt_expose_device_noalloc: bad argument");
+    const size_t n = (size_t)width * (size_t)height;
+    if (n > (size_t)RT_NOALLOC_MAX_PIXELS)
+        return fail(h, RT_ERR_ARG, "rt_expose_device_noalloc: frame of " + std::to_string(n) + " pixels exceeds RT_NOALLOC_MAX_PIXELS (" +
+                                   std::to_string(RT_NOALLOC_MAX_PIXELS) + "); use rt_expose_device");
+    unsigned char* const base = (h->device >= 0 && h->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[h->device] : nullptr;
+    if (!base) return fail(h, RT_ERR_HIP, "rt_expose_device_noalloc: the static buffer of this device was not set up by rt_create");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double* taps = (const double*)base;
+    double* buf[2] = {(double*)(base + NOALLOC_TAPS_BYTES), (double*)(base + NOALLOC_TAPS_BYTES + NOALLOC_BUF_BYTES)};
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > (unsigned)h->cu_count * 32u) grid = (unsigned)h->cu_count * 32u;
+    if (num_blurs == 0) {
+        hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)nullptr, d_img, n, exposure);
+        HIP_TRY(h, hipGetLastError());
+        return RT_OK;
+    }
+    unsigned g3 = (unsigned)((n * 3 + 255) / 256);
+    if (g3 > (unsigned)h->cu_count * 32u) g3 = (unsigned)h->cu_count * 32u;
+    hipLaunchKernelGGL(expose_mask_kernel, dim3(g3), dim3(256), 0, st, d_rgb, buf[0], n * 3, exposure);
+    int cur = 0;
+    const dim3 bgrid((width + BLOOM_T - 1) / BLOOM_T, (height + BLOOM_T - 1) / BLOOM_T, 3);
+    for (int b = 0; b < num_blurs; b++) {
+        hipLaunchKernelGGL(bloom_kernel, bgrid, dim3(BLOOM_T * BLOOM_T), 0, st, (const double*)buf[cur], buf[cur ^ 1], width, height, taps,
+                           (const int*)nullptr);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)buf[cur], d_img, n, exposure);
     HIP_TRY(h, hipGetLastError());
     return RT_OK;
 }

@@ -1,0 +1,49 @@
+"""rt_expose_device_noalloc -- expose() on the library's fixed per-GPU buffer, for callers that cannot allocate device
+memory -- against rt_expose_device through the C ABI: every packed pixel equal (integer output), on two calls in a row,
+the second on a smaller frame (the shared buffer then still holds the first call's values), plus the size limit."""
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _frame(h, w, exposure, seed):
+    rng = np.random.default_rng(seed)
+    rgb = rng.uniform(0, 1.3 / exposure, (h, w, 3))                    # about a quarter of the channels saturate
+    rgb[h // 2, w // 3] = [np.nan, np.inf, -1.0]
+    rgb[0, 0] = [5.0, 0.0, 1e300]
+    return rgb
+
+
+def _both(renderer, rgb, exposure, blurs):
+    h, w, _ = rgb.shape
+    st = torch.cuda.current_stream().cuda_stream
+    d_rgb = torch.from_numpy(np.ascontiguousarray(rgb)).to("cuda:0")
+    want = torch.full((h, w), -7, dtype=torch.int32, device="cuda:0")
+    got = torch.full((h, w), -9, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    renderer.expose_device(d_rgb.data_ptr(), w, h, exposure, blurs, want.data_ptr(), st)
+    renderer.expose_device_noalloc(d_rgb.data_ptr(), w, h, exposure, blurs, got.data_ptr(), st)
+    torch.cuda.synchronize()
+    return got.cpu().numpy(), want.cpu().numpy()
+
+
+def test_noalloc_expose_equals_expose_twice_in_a_row(renderer):
+    for (h, w, exposure, blurs) in ((300, 400, 0.9, 3), (90, 161, 1.4, 2), (17, 9, 1.0, 1), (33, 47, 0.7, 0)):
+        got, want = _both(renderer, _frame(h, w, exposure, h * w), exposure, blurs)
+        assert np.array_equal(got, want), f"{h}x{w}, {blurs} passes: {int((got != want).sum())} packed pixels differ"
+        assert (want != -7).all()
+
+
+def test_noalloc_expose_largest_frame_and_limit(renderer):
+    got, want = _both(renderer, _frame(512, 512, 1.0, 3), 1.0, 1)        # exactly RT_NOALLOC_MAX_PIXELS
+    assert np.array_equal(got, want)
+    d = torch.zeros((513, 512, 3), dtype=torch.float64, device="cuda:0")
+    o = torch.zeros((513, 512), dtype=torch.int32, device="cuda:0")
+    with pytest.raises(api.RtError) as e:
+        renderer.expose_device_noalloc(d.data_ptr(), 512, 513, 1.0, 1, o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert e.value.code == -1 and "RT_NOALLOC_MAX_PIXELS" in str(e.value)
+    assert api.NOALLOC_MAX_PIXELS == 512 * 512
