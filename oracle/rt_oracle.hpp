@@ -62,6 +62,14 @@ struct SceneD {
     const double* verts = nullptr;
 };
 
+// (int)x as the reference's x86 build converts a double (cvttsd2si): truncation toward zero, INT_MIN when the value is
+// out of int range or NaN.  Used wherever the reference casts a double that a scene can push out of range
+// (src/geometry.cpp:108-109 checker index, :15-23 Color::to_int).
+static inline int cvttsd2si(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000u;
+    return (int)v;
+}
+
 // ------------------------------------------------------------------------- RNG
 // std::default_random_engine of libstdc++ is minstd_rand0: x <- 16807 x mod
 // (2^31 - 1), operator() returns the new state, min 1, max 2147483646; a default
@@ -241,8 +249,10 @@ struct Tracer {
     // Plane::get_material, src/geometry.cpp:106-116 (5-unit checker on world x, z)
     static int plane_material(const Prim& pl, const V& p) {
         V v = psub(p, pl.a);
-        int x = (int)(v.v[0] / R(5)) % 2;
-        int z = (int)(v.v[2] / R(5)) % 2;
+        // (int) of an out-of-range double is undefined in C++; the reference's x86 build converts with cvttsd2si, which
+        // returns INT_MIN for it (and for NaN): stated here so that the result does not depend on this file's compiler
+        int x = cvttsd2si((double)(v.v[0] / R(5))) % 2;
+        int z = cvttsd2si((double)(v.v[2] / R(5))) % 2;
         if (v.v[0] < 0) x = -x;
         if (v.v[2] < 0) z = -z;
         int m = (x == z) ? pl.mat0 : pl.mat1;
@@ -518,7 +528,7 @@ static inline void expose(int W, int H, double exposure, int num_blurs, int n_wo
     for (size_t i = 0; i < (size_t)W * H * 3; i++) rgb[i] = rgb[i] + cur[i];
     double mx = 1.0 / exposure;
     for (size_t i = 0; i < (size_t)W * H; i++) {
-        int r = 255 * rgb[3 * i] / mx, g = 255 * rgb[3 * i + 1] / mx, b = 255 * rgb[3 * i + 2] / mx;
+        int r = cvttsd2si(255 * rgb[3 * i] / mx), g = cvttsd2si(255 * rgb[3 * i + 1] / mx), b = cvttsd2si(255 * rgb[3 * i + 2] / mx);
         if (r > 255) r = 255;
         if (g > 255) g = 255;
         if (b > 255) b = 255;

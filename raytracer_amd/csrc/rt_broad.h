@@ -43,6 +43,17 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax) {
     r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);
     const float bc = (float)(o2 - (double)E0) - __builtin_fabsf((float)o2) * (4.0f * F32_U);
     r.c = make_float4(Eh * 1.00001f, bc, 0.0f, 0.0f);
+    // A ray whose float image is not of ordinary size -- NaN, infinite, or so large that the squares above leave the float
+    // range (inf - inf is a NaN of either sign, and the keep rule reads a sign) -- gets constants under which every record
+    // is kept and none is "behind": s = the record's own fourth word, thr = -inf.  The exact test then sees every solid.
+    const float lim = 1e15f;
+    const bool ordinary = (__builtin_fabsf(ox) < lim) & (__builtin_fabsf(oy) < lim) & (__builtin_fabsf(oz) < lim) &
+                          (__builtin_fabsf(fx) < lim) & (__builtin_fabsf(fy) < lim) & (__builtin_fabsf(fz) < lim);
+    if (!ordinary) {
+        r.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.b = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+        r.c = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    }
     return r;
 }
 

@@ -25,7 +25,7 @@ struct rt_context {
     void* d_prims = nullptr;
     void* d_verts = nullptr;
     void* d_mats = nullptr;
-    void* d_always = nullptr; int n_always = 0, always_doubles = 0;
+    void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;
     // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
     uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
     GridD grid{}; bool grid_ok = false; size_t grid_items = 0;
@@ -72,6 +72,7 @@ struct rt_context {
     int chunk_records = 8192;  // LDS window in records (16 bytes each)
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
     int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
     double grid_density = 1.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY); 0.5 to 8 measured: flat optimum, 1 best on C4
 };
@@ -218,6 +219,37 @@ bool face_bound(const double* v, int nv, const double* n, double* centre, double
     return std::isfinite(*radius);
 }
 
+// Axis code of a plane or face for narrow_always' collapsed test, 0 when the solid does not qualify.  Qualifies: the unit
+// normal is exactly +-(unit vector k) -> code +-(k + 1); and, for a face, every vertex whose to_next is not zero has an edge
+// e_i = v_i - v_i+1 with exactly one non-zero component L, |L| >= 1 and |to_next| >= 1, all coordinates below 1e300.  lo/hi
+// receive the coordinate box the vertex tests amount to: vertex i rejects p iff sign(L to_next) (v_i[a] - p[a]) < 0.
+int box_code(int kind, const double* n, const FaceV* fv, int nv, double* lo, double* hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = -INFINITY; hi[a] = INFINITY; }
+    int k = -1;
+    for (int a = 0; a < 3; a++) {
+        if (n[a] == 1.0 || n[a] == -1.0) { if (k >= 0) return 0; k = a; }
+        else if (n[a] != 0.0) return 0;             // also rejects NaN
+    }
+    if (k < 0) return 0;
+    if (kind == RT_KIND_FACE) {
+        for (int i = 0; i < nv; i++) {
+            const FaceV& f = fv[i];
+            for (int a = 0; a < 3; a++) if (!(fabs(f.v[a]) < 1e300) || !(fabs(f.e[a]) < 1e300)) return 0;
+            if (!std::isfinite(f.to_next)) return 0;
+            if (f.to_next == 0.0) continue;          // (anything) * 0 is never negative: no constraint
+            int ax = -1;
+            for (int a = 0; a < 3; a++) if (f.e[a] != 0.0) { if (ax >= 0) return 0; ax = a; }
+            if (ax < 0) return 0;
+            const double L = f.e[ax];
+            if (!(fabs(L) >= 1.0) || !(fabs(f.to_next) >= 1.0)) return 0;
+            const bool pos = (L > 0) == (f.to_next > 0);
+            if (pos) { if (f.v[ax] < hi[ax]) hi[ax] = f.v[ax]; }      // rejects p[ax] > v: p[ax] <= v
+            else     { if (f.v[ax] > lo[ax]) lo[ax] = f.v[ax]; }      // rejects p[ax] < v: p[ax] >= v
+        }
+    }
+    return n[k] > 0 ? k + 1 : -(k + 1);
+}
+
 // Uniform grid over the bounded solids that are not in the always table, for walk_kernel.  bc/br: bounding sphere of
 // every solid (radius < 0: unbounded), T: the translation of the float coordinates.  A solid is listed in every cell
 // that the box of its bounding sphere, grown by `pad`, overlaps.  Returns false when the scene cannot use the grid
@@ -362,7 +394,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.prims = (const PrimD*)h->d_prims;
     kp.verts = (const FaceV*)h->d_verts;
     kp.mats = (const MatD*)h->d_mats;
-    kp.always = (const double*)h->d_always; kp.n_always = h->n_always; kp.always_doubles = h->always_doubles;
+    kp.always = (const double*)h->d_always; kp.n_always = h->n_always; kp.always_doubles = h->always_doubles; kp.n_box = h->n_box;
     kp.ctrl = h->d_ctrl;
 }
 

@@ -117,6 +117,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_CHUNK_RECORDS")) rt_set_option(h, RT_OPT_CHUNK_RECORDS, atoi(e));
     if (const char* e = getenv("RT_OVERLAP")) rt_set_option(h, RT_OPT_OVERLAP, atoi(e));
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
+    if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
     return RT_OK;
@@ -364,11 +365,24 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         }
     }
 
-    // the table of the "always" solids
+    // the table of the "always" solids: box entries first (narrow_always), then the others
     std::vector<double> alw;
-    int n_always = 0;
+    int n_always = 0, n_box = 0;
+    std::vector<char> is_box((size_t)n_prims + 1, 0);
     for (int i = 0; i < n_prims; i++) {
-        if (!always[i]) continue;
+        if (!always[i] || pd[i].kind == RT_KIND_SPHERE || h->no_box) continue;
+        if (!(fabs(pd[i].a[0]) < 1e300 && fabs(pd[i].a[1]) < 1e300 && fabs(pd[i].a[2]) < 1e300)) continue;
+        const int nv = pd[i].kind == RT_KIND_FACE ? pd[i].vcnt : 0;
+        double blo[3], bhi[3];
+        const int code = box_code(pd[i].kind, pd[i].n, vd.data() + (nv ? pd[i].voff : 0), nv, blo, bhi);
+        if (!code) continue;
+        const int k = (code < 0 ? -code : code) - 1;
+        const double ent[ALW_BOX] = {(double)code, (double)i, pd[i].a[k], 0.0, blo[0], blo[1], blo[2], 0.0, bhi[0], bhi[1], bhi[2], 0.0};
+        alw.insert(alw.end(), ent, ent + ALW_BOX);
+        is_box[i] = 1; n_box++; n_always++;
+    }
+    for (int i = 0; i < n_prims; i++) {
+        if (!always[i] || is_box[i]) continue;
         const int nv = pd[i].kind == RT_KIND_FACE ? pd[i].vcnt : 0;
         const double head[ALW_HEAD] = {(double)pd[i].kind, (double)i, (double)nv, 0.0, pd[i].a[0], pd[i].a[1], pd[i].a[2],
                                        pd[i].radius, pd[i].n[0], pd[i].n[1], pd[i].n[2], 0.0};
@@ -401,7 +415,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     }
     HIP_TRY(h, hipMalloc(&h->d_always, alw.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->n_always = n_always; h->always_doubles = always_doubles;
+    h->n_always = n_always; h->always_doubles = always_doubles; h->n_box = n_box;
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));

@@ -192,11 +192,18 @@ DEV d3 refraction_dir(d3 d, d3 normal, double rindex, double n_cur) {
     return dnorm(dadd(dscale(d, ratio), dscale(an, k)));
 }
 
-// Plane::get_material, geometry.cpp:106-116
+// (int)x as the reference's compiler converts it (cvttsd2si): truncation, 0x80000000 when out of range or NaN
+DEV int to_int_x86(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000u;
+    return (int)v;
+}
+
+// Plane::get_material, geometry.cpp:106-116.  A hit further than 2^31 * 5 units from the plane's point overflows the
+// reference's int conversion, which on its x86 target yields INT_MIN (an even number): the checker is uniform out there.
 DEV int plane_material(double ax, double az, int mat0, int mat1, d3 p) {
     double vx = p.x - ax, vz = p.z - az;
-    int x = (int)(vx / 5.0) % 2;
-    int z = (int)(vz / 5.0) % 2;
+    int x = to_int_x86(vx / 5.0) % 2;
+    int z = to_int_x86(vz / 5.0) % 2;
     if (vx < 0.0) x = -x;
     if (vz < 0.0) z = -z;
     int m = (x == z) ? mat0 : mat1;

@@ -15,6 +15,12 @@ namespace {
 #ifndef SHADE_PROFILE
 #define SHADE_PROFILE 0
 #endif
+#ifndef DIAG_TWICE_ALWAYS      // diagnostic builds: run a section of shade_kernel twice
+#define DIAG_TWICE_ALWAYS 0
+#endif
+#ifndef DIAG_TWICE_CAND
+#define DIAG_TWICE_CAND 0
+#endif
 #ifndef WALK_DEBUG
 #define WALK_DEBUG 0
 #endif

@@ -51,8 +51,6 @@ __global__ __launch_bounds__(BLOOM_T * BLOOM_T) void bloom_kernel(const double* 
     if (x < W && y < H) dst[((size_t)y * W + x) * 3 + ch] = c;
 }
 
-DEV int to_int_x86(double v);
-
 // ---- expose() before the gather: every rank blooms and packs the rows it rendered -----------------------------
 // B0 (main.cpp:198-205) is three bits per pixel.  Each rank reduces its rows to those bits (expose_bits_kernel), the
 // ranks all-gather them (1 byte per pixel), and each rank then runs the blur passes on the 16-row blocks its own rows
@@ -105,12 +103,6 @@ __global__ void expose_pack_rows_kernel(const double* rgb, const double* bloom, 
         }
         img[i] = (int)(((unsigned)v[0] << 16) + ((unsigned)v[1] << 8) + (unsigned)v[2]);
     }
-}
-
-// (int)x as the reference's compiler converts it (cvttsd2si): truncation, 0x80000000 when out of range or NaN
-DEV int to_int_x86(double v) {
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000u;
-    return (int)v;
 }
 
 // main.cpp:225-227 + 237-241 with Color::to_int (geometry.cpp:15-23).  bloom == nullptr: no blur pass was

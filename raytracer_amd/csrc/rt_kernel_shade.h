@@ -35,8 +35,17 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
         uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
         if (n > 0u) cur = cl[0];
         if (n > 1u) nxt = cl[cstride];
-        narrow_always(alw, w.kp.n_always, o, d, h);
+        // a ray the box entries' test is not proven for joins the heavy rays: every solid through the general test
+        heavy = narrow_always<false>(alw, w.kp.n_always, w.kp.n_box, o, d, w.kp, h);
+#if DIAG_TWICE_ALWAYS      // diagnostic build: the section's cost is the frame time it adds (re-considering a hit changes nothing)
+        __builtin_amdgcn_sched_barrier(0);
+        narrow_always<false>(alw + (w.kp.n_always > 1000 ? 1 : 0), w.kp.n_always, w.kp.n_box, o, d, w.kp, h);
+#endif
         ncand_total += (unsigned)w.kp.n_always;
+#if DIAG_TWICE_CAND
+        for (int rep = 0; rep < 2; rep++) {
+        if (rep) { if (n > 0u) cur = cl[0]; if (n > 1u) nxt = cl[cstride]; }
+#endif
         for (unsigned e = 0; e < n; e++) {
             const uint2 ent = cur;
             cur = nxt;
@@ -52,6 +61,9 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
                 if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
             }
         }
+#if DIAG_TWICE_CAND
+        }
+#endif
     }
     unsigned long long hm = __ballot(heavy);
     while (hm) {

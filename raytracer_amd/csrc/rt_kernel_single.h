@@ -60,7 +60,7 @@ DEV Hit closest_hit_block(const KParams& kp, float4* lds, bool lockstep, bool al
         }
     }
     if (alive) {
-        narrow_always(kp.always, kp.n_always, o, d, h);
+        narrow_always<true>(kp.always, kp.n_always, kp.n_box, o, d, kp, h);
         ncand_total += (unsigned)kp.n_always;
         narrow();
     }

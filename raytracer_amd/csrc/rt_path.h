@@ -206,11 +206,115 @@ DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts)
 }
 DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) { consider(narrow_point(idx, o, d, kp.prims, kp.verts), idx, o, h); }
 
-// exact test of every "always" solid, read from `tab` (LDS or global) at wave-uniform addresses
-constexpr int ALW_HEAD = 12;
-DEV void narrow_always(const double* tab, int n_always, d3 o, d3 d, Hit& h) {
-    int off = 0;
-    for (int a = 0; a < n_always; a++) {
+// Exact test of every "always" solid, read from `tab` (LDS or global) at wave-uniform addresses.  The table holds first
+// n_box "box" entries of ALW_BOX doubles, then the others: ALW_HEAD doubles (kind, file index, vertex count, -, point[3],
+// radius, normal[3], -) and 8 doubles per face vertex (FaceV).
+//
+// A box entry is a plane or face whose unit normal is exactly +-(unit vector k) and, for a face, whose every edge runs
+// along one coordinate axis (box_code on the host): a wall of an axis-aligned room.  For those the reference's
+// operation sequence collapses, bit for bit, as long as origin, direction and hit point are finite and below 1e300:
+//   * Vector::dot with a vector that has one component +-1 and two zeros returns the other vector's component (or its
+//     negation): every other product is a zero and x + (+-0) = x.  So (P - o).n = +-(P_k - o_k) and n.d = +-d_k; a
+//     zero result may differ in sign, which changes nothing (t = +-0 fails t >= 0.001, a zero divisor gives |t| = inf or
+//     NaN, both rejected).
+//   * Face::intersect's test of vertex i, (e_i.(v_i - p)) * to_next_i < 0 with e_i = (0, L, 0) say, is
+//     fl(fl(L * fl(v_i.y - p.y)) * to_next_i) < 0.  The sign of a floating-point difference is exact, and with |L| >= 1
+//     and |to_next_i| >= 1 (checked on the host) neither product can round to zero unless the difference is zero, so
+//     the test is: sign(L * to_next_i) * (v_i.y - p.y) < 0, i.e. p.y beyond v_i.y on one side.  All vertices together:
+//     lo <= p <= hi per coordinate (+-inf where nothing constrains).
+// The division, the point o + t d and the squared distance are the reference's own operations.  The test is written
+// without a branch (every lane divides; the outcome is a predicate) and two entries are loaded and evaluated per step.
+// Entry: code (+-(k+1): normal = sign * unit vector k), file index, P_k, -, lo[3], -, hi[3], -.
+constexpr int ALW_HEAD = 12, ALW_BOX = 12;
+
+struct BoxOut { bool valid, odd; double q; d3 p; };
+
+DEV BoxOut box_test(const double* r, int code, bool ray_ok, d3 o, d3 d) {
+    const double inf = __builtin_inf(), big = 1e300;
+    // the whole entry up front, and every comparison evaluated (& not &&): no branch, no load behind a comparison
+    const double2 e2 = ld2(r + 2), l01 = ld2(r + 4), l2 = ld2(r + 6), h01 = ld2(r + 8), h2 = ld2(r + 10);
+    const int k = (code < 0 ? -code : code) - 1;
+    const double ok = k == 0 ? o.x : (k == 1 ? o.y : o.z);
+    const double dk = k == 0 ? d.x : (k == 1 ? d.y : d.z);
+    const double v = e2.x - ok;
+    const double num = code < 0 ? -v : v, den = code < 0 ? -dk : dk;
+    const double t = num / den;
+    const bool t_ok = (t >= RT_EPS) & (t < inf);                 // false for NaN and -inf
+    BoxOut b;
+    b.p = dalong(o, t, d);
+    const bool small = (__builtin_fabs(b.p.x) < big) & (__builtin_fabs(b.p.y) < big) & (__builtin_fabs(b.p.z) < big);
+    const bool inside = (b.p.x >= l01.x) & (b.p.x <= h01.x) & (b.p.y >= l01.y) & (b.p.y <= h01.y) & (b.p.z >= l2.x) & (b.p.z <= h2.x);
+    b.valid = ray_ok & t_ok & small & inside;
+    b.odd = ray_ok & t_ok & !small;                              // huge or overflowed point: the reference's own sequence decides
+    const d3 w = dsub(b.p, o);
+    b.q = ddot(w, w);
+    return b;
+}
+
+// consider_q under a predicate, the common outcomes without a branch
+DEV void consider_if(bool valid, double q, d3 p, int idx, Hit& h) {
+    const double band = 8.8817841970012523e-16;      // 2^-50, see consider_q
+    const bool nearer = q < h.q * (1.0 - band);
+    const bool tie = valid & !nearer & !(q > h.q * (1.0 + band));
+    bool take = valid & nearer;
+    if (tie) {
+        const double len = __builtin_sqrt(q), hl = __builtin_sqrt(h.q);
+        take = hl > len || (hl == len && idx < h.idx);
+    }
+    h.q = take ? q : h.q; h.idx = take ? idx : h.idx;
+    h.p.x = take ? p.x : h.p.x; h.p.y = take ? p.y : h.p.y; h.p.z = take ? p.z : h.p.z;
+}
+
+DEV d3 face_verts_tab(const double* r, int nv, d3 p0) {
+    bool miss = false;
+    for (int i = 0; i < nv; i++) {
+        const double* v = r + ALW_HEAD + 8 * i;
+        double to_p = ddot(dmk(v[3], v[4], v[5]), dsub(dmk(v[0], v[1], v[2]), p0));
+        if (to_p * v[6] < 0.0) miss = true;
+    }
+    if (miss) p0 = dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+    return p0;
+}
+
+// Returns true for a ray the box entries' test is not proven for.  With REDO its box entries are then tested here through
+// the general test; without it the caller has to test them (or every solid) itself.
+template <bool REDO>
+DEV bool narrow_always(const double* tab, int n_always, int n_box, d3 o, d3 d, const KParams& kp, Hit& h) {
+    const double big = 1e300;
+    // every component finite and far from overflow, so that no difference with a table coordinate (all below 1e300 too)
+    // overflows and every "x * 0" of the reference's dot products is a zero; |x| < big is false for NaN as well
+    const bool ray_ok = (__builtin_fabs(o.x) < big) & (__builtin_fabs(o.y) < big) & (__builtin_fabs(o.z) < big) &
+                        (__builtin_fabs(d.x) < big) & (__builtin_fabs(d.y) < big) & (__builtin_fabs(d.z) < big);
+    bool odd = !ray_ok & (n_box > 0);
+    int a = 0;
+    for (; a + 1 < n_box; a += 2) {
+        const double* r0 = tab + ALW_BOX * a;
+        const double* r1 = r0 + ALW_BOX;
+        const int c0 = __builtin_amdgcn_readfirstlane((int)r0[0]), i0 = __builtin_amdgcn_readfirstlane((int)r0[1]);
+        const int c1 = __builtin_amdgcn_readfirstlane((int)r1[0]), i1 = __builtin_amdgcn_readfirstlane((int)r1[1]);
+        const BoxOut b0 = box_test(r0, c0, ray_ok, o, d);
+        const BoxOut b1 = box_test(r1, c1, ray_ok, o, d);
+        consider_if(b0.valid, b0.q, b0.p, i0, h);
+        consider_if(b1.valid, b1.q, b1.p, i1, h);
+        odd = odd | b0.odd | b1.odd;
+    }
+    if (a < n_box) {
+        const double* r0 = tab + ALW_BOX * a;
+        const int c0 = __builtin_amdgcn_readfirstlane((int)r0[0]), i0 = __builtin_amdgcn_readfirstlane((int)r0[1]);
+        const BoxOut b0 = box_test(r0, c0, ray_ok, o, d);
+        consider_if(b0.valid, b0.q, b0.p, i0, h);
+        odd = odd | b0.odd;
+    }
+    if (REDO && odd) {
+        // all box entries through the general test; re-considering a solid that was already accepted changes nothing (the
+        // acceptance is a strict order)
+        for (int b = 0; b < n_box; b++) {
+            const int idx = __builtin_amdgcn_readfirstlane((int)tab[ALW_BOX * b + 1]);
+            narrow_one(idx, o, d, kp, h);
+        }
+    }
+    int off = ALW_BOX * n_box;
+    for (a = n_box; a < n_always; a++) {
         const double* r = tab + off;
         const int kind = __builtin_amdgcn_readfirstlane((int)r[0]);
         const int idx = __builtin_amdgcn_readfirstlane((int)r[1]);
@@ -220,19 +324,12 @@ DEV void narrow_always(const double* tab, int n_always, d3 o, d3 d, Hit& h) {
             p0 = sphere_point(dmk(r[4], r[5], r[6]), r[7], o, d);
         } else {
             p0 = plane_point(dmk(r[4], r[5], r[6]), dmk(r[8], r[9], r[10]), o, d);
-            if (kind == RT_KIND_FACE && !dnan(p0.x)) {
-                bool miss = false;
-                for (int i = 0; i < nv; i++) {
-                    const double* v = r + ALW_HEAD + 8 * i;
-                    double to_p = ddot(dmk(v[3], v[4], v[5]), dsub(dmk(v[0], v[1], v[2]), p0));
-                    if (to_p * v[6] < 0.0) miss = true;
-                }
-                if (miss) p0 = dmk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
-            }
+            if (kind == RT_KIND_FACE && !dnan(p0.x)) p0 = face_verts_tab(r, nv, p0);
         }
         consider(p0, idx, o, h);
         off += ALW_HEAD + 8 * nv;
     }
+    return odd;
 }
 
 DEV void map_item_to_pixel(unsigned item, const KParams& kp, int& px, int& py) {

@@ -62,9 +62,9 @@ struct KParams {
     const FaceV* verts;
     const MatD* mats;
     const double* always;    // solids every ray must test exactly (unbounded or very large bounding sphere): per solid
-                             // ALW_HEAD doubles (kind, file index, vertex count, -, point[3], radius, normal[3], -) and
-                             // 8 doubles per face vertex (FaceV); their broad-phase records are padding
+                             // layout at narrow_always; their broad-phase records are padding
     int n_always, always_doubles;
+    int n_box;               // the first n_box entries of `always` are box entries (narrow_always)
     double* rgb;
     int* hit_ids;
     unsigned long long* stream_rays;

@@ -72,6 +72,16 @@ def _scenes():
     yield "acute_triangle_and_parallelogram", _header(5, width=64, height=36), [FLOOR, CEIL_LIGHT, atri, para, _sphere((12, -8, -4), 3)]
     small = [_face([(x, y, -12), (x + 1.5, y, -12), (x + 0.75, y + 1.2, -12)], (0, 0, 1)) for x in (-12, -6, 0, 6, 12) for y in (-9, -4, 1)]
     yield "small_acute_triangles", _header(2 + len(small), width=64, height=36, depth=2), [FLOOR, CEIL_LIGHT] + small
+    # Room walls as the always-tested "box" solids see them (axis-aligned normal, edges along the axes: the device tests
+    # them by coordinate ranges) and walls that must NOT qualify: an edge shorter than 1, vertices in the other sense
+    # of rotation, a normal along -z with a negative-x wall, a wall whose normal is not its vertices' plane.
+    strip = _face([(-18, -10, -25), (-17.5, -10, -25), (-17.5, 12, -25), (-18, 12, -25)], (0, 0, 1))        # 0.5 wide: general test
+    back_cw = _face([(-20, -12, -30), (-20, 14, -30), (20, 14, -30), (20, -12, -30)], (0, 0, 1))            # clockwise order
+    left = _face([(-20, -12, -30), (-20, 14, -30), (-20, 14, 10), (-20, -12, 10)], (1, 0, 0))
+    right_neg = _face([(20, -12, 10), (20, 14, 10), (20, 14, -30), (20, -12, -30)], (-1, 0, 0))
+    tilted_normal = _face([(5, -12, -29), (12, -12, -29), (12, 2, -29), (5, 2, -29)], (0.1, 0, 1))          # normal off the axis
+    yield "box_walls_and_non_box_walls", _header(9, width=64, height=36), [FLOOR, CEIL_LIGHT, back_cw, left, right_neg, strip,
+                                                                            tilted_normal, _sphere((0, -7, -12), 5), _sphere((-9, -8, -6), 3, glass=1.5)]
     many = [FLOOR, CEIL_LIGHT] + [_sphere((-18 + 1.2 * (i % 31), -10 + 1.2 * (i // 31), -12 - 0.1 * i), 0.5) for i in range(90)]
     yield "row_of_spheres_overflowing_lists", _header(len(many), width=64, height=36, depth=2, lens=0.0), many
 

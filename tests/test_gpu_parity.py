@@ -161,3 +161,17 @@ def test_moved_camera_matches_oracle(renderer, golden_dir):
     base = S.loads(text)
     renderer.upload(base)
     assert not np.array_equal(renderer.render()["rgb"], g["rgb"])       # the key has an effect
+
+
+def test_camera_beyond_the_box_test_range(renderer, golden_dir):
+    """Origins of 1e200: beyond the range for which the always-tested walls' coordinate-range test is proven, so every
+    such ray takes the general test (whole-wave scan in the pipeline, the loop in the single-kernel renderer).  Pinned
+    by the oracle only (no reference output exists for a moved camera)."""
+    text = open(os.path.join(golden_dir, "small_room.scene.json")).read()
+    sc = S.loads(text.replace('{"num_threads"', '{"camera": [0.5, -0.25, 1e200], "num_threads"', 1))
+    for mode in (api.MODE_PIPELINE, api.MODE_SINGLE_KERNEL):
+        try:
+            renderer.set_option(api.OPT_MODE, mode)
+            _compare(renderer, sc, f"small_room[camera 1e200, mode {mode}]")
+        finally:
+            renderer.set_option(api.OPT_MODE, api.MODE_PIPELINE)
