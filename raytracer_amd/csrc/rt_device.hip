@@ -223,6 +223,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         }
         o.gloss_thr = it;
         o.sexp = m[RT_MT_SEXP];
+        o.inv_sexp = 1.0 / o.sexp;
         o.rindex = m[RT_MT_RINDEX];
     }
 
@@ -617,7 +618,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);
                 if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
-                hipLaunchKernelGGL(shade_kernel, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), shade_lds, ss[p], w);
+                if (it == 0) hipLaunchKernelGGL(shade_kernel<true>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), shade_lds, ss[p], w);
+                else hipLaunchKernelGGL(shade_kernel<false>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), shade_lds, ss[p], w);
             }
         }
         e = hipGetLastError();

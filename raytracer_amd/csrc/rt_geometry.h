@@ -48,8 +48,16 @@ DEV unsigned rng_next(unsigned& s) {
     s = x;
     return x;
 }
-// (double)g() / g.max(), main.cpp:255
-DEV double rng_uniform(unsigned& s) { return (double)rng_next(s) / 2147483646.0; }
+// (double)g() / g.max(), main.cpp:255.  The divisor is a constant and the dividend an integer below 2^31, so the quotient
+// is taken with the correctly rounded reciprocal y and one correction step, q = g y, q + (g - b q) y: three operations in
+// place of a division's thirteen.  It IS the IEEE quotient for every one of the 2^31 - 2 possible draws
+// (tools/check_rng_div.c compares them all).
+DEV double rng_uniform(unsigned& s) {
+    const double b = 2147483646.0, y = 0x1.00000004p-31;          // y = fl(1 / b)
+    const double g = (double)rng_next(s);
+    const double q = g * y;
+    return __builtin_fma(__builtin_fma(-b, q, g), y, q);
+}
 
 __host__ __device__ inline unsigned pixel_seed(unsigned pixel_index, unsigned frame_seed) {
     unsigned h = pixel_index * 0x9E3779B1u ^ frame_seed;
@@ -152,7 +160,7 @@ DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
 // branch (:48-77, power-cosine lobe about the mirror direction, rejection loop) and the diffuse branch
 // (:78-103, uniform hemisphere about the normal) build their sample the same way about different axes;
 // they share one instruction stream here, each lane keeping its own branch's operation sequence.
-DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double sexp, unsigned& rng, unsigned* err, unsigned item) {
+DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double inv_exp, unsigned& rng, unsigned* err, unsigned item) {
     const double PI = 3.14159265358979323846;
     const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
     const bool glossy = rng_next(rng) < gloss_thr;
@@ -161,7 +169,6 @@ DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double sexp, unsigned
     const d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), axis));
     double sint, cost;
     rtm::sincosd(theta, &sint, &cost);
-    const double inv_exp = 1.0 / sexp;
     d3 nd = dmk(0.0, 0.0, 0.0);
     for (int iter = 0;; iter++) {
         const double u1 = rng_uniform(rng);

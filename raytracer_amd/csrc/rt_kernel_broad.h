@@ -111,17 +111,26 @@ DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathStat
     w.cand_cnt[(size_t)q * w.slots + pos] = 0u;        // broad_kernel's slices add to it
 }
 
+// the state in which the pixel of `slot` starts its first path: RNG seeded from the pixel's frame index, camera ray
+DEV void start_state(const WfParams& w, unsigned slot, PathState& s) {
+    const unsigned item = w.item_base + slot;
+    map_item_to_pixel(item, w.kp, s.px, s.py);
+    s.rng = pixel_seed((unsigned)(s.py * w.kp.width + s.px), w.kp.frame_seed);
+    s.pv_mat = 0; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
+    s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
+    begin_pixel(s, item, w.kp);
+}
+
+// Queue 0 = every pixel slot in order.  Only what broad_kernel reads is written: the float ray record and a zero entry
+// count; the first round's shade_kernel rebuilds the start state itself (start_state).
 __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < w.slots; slot += stride) {
         PathState s;
-        const unsigned item = w.item_base + slot;
-        map_item_to_pixel(item, w.kp, s.px, s.py);
-        s.rng = pixel_seed((unsigned)(s.py * w.kp.width + s.px), w.kp.frame_seed);
-        s.pv_mat = 0; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
-        s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
-        begin_pixel(s, item, w.kp);
-        emit_ray(w, slot, slot, s, 0);
+        start_state(w, slot, s);
+        const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
+        w.rec[0][slot] = r.a; w.rec[1][slot] = r.b;
+        w.cand_cnt[slot] = 0u;
     }
 }
 

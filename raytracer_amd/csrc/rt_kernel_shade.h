@@ -90,7 +90,11 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
     return h;
 }
 
-// exact narrow phase + one segment of add_to_path per queued ray; survivors are packed into the next queue
+// exact narrow phase + one segment of add_to_path per queued ray; survivors are packed into the next queue.
+// FIRST: the round of the camera rays.  Queue position = pixel slot and the path state is the start state, which the
+// lane rebuilds from the pixel index (the same operations as init_kernel, hence the same bits) instead of reading it:
+// init_kernel then writes 36 bytes per pixel instead of 152 and this round reads none of them back.
+template <bool FIRST>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w) {
     extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
@@ -122,7 +126,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         SHADE_TICK(0);
         // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
         d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
-        if (live) {
+        unsigned rng0 = 0;
+        if (FIRST) {
+            if (live) {
+                // only the ray and the RNG state stay in registers during the closest-hit search
+                PathState t0;
+                slot = pos;
+                start_state(w, slot, t0);
+                ro = t0.o; rd = t0.d; rng0 = t0.rng;
+            }
+        } else if (live) {
             const double2* sd = w.sd[qi] + pos;
             const size_t n = w.slots;
             const double2 p0 = sd[0], p1 = sd[n], p2 = sd[2 * n];
@@ -132,8 +145,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         const Hit h = find_hit(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         if (live) {
-            slot = w.queue[qi][pos];
-            load_state(w, qi, pos, slot, ro, rd, s);
+            if (FIRST) {
+                map_item_to_pixel(w.item_base + slot, w.kp, s.px, s.py);
+                s.rng = rng0; s.sample = 0; s.remaining = w.kp.depth; s.nverts = 0; s.pv_mat = 0; s.flags = FL_FIRST_SEG;
+                s.out_index = w.item_base + slot; s.n_cur = 1.0; s.acc0 = s.acc1 = s.acc2 = 0.0;
+                s.o = ro; s.d = rd; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
+                s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
+            } else {
+                slot = w.queue[qi][pos];
+                load_state(w, qi, pos, slot, ro, rd, s);
+            }
             nrays++;
             FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
             alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);

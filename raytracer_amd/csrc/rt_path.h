@@ -85,9 +85,9 @@ DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, 
         start_path(s, kp);
         return true;
     }
-    const double n = (double)kp.spp;
     double* out = kp.rgb + (size_t)s.out_index * 3;
-    out[0] = s.acc0 / n; out[1] = s.acc1 / n; out[2] = s.acc2 / n;
+    if (kp.spp == 1) { out[0] = s.acc0; out[1] = s.acc1; out[2] = s.acc2; }      // x / 1 = x: three divisions saved per pixel
+    else { const double n = (double)kp.spp; out[0] = s.acc0 / n; out[1] = s.acc1 / n; out[2] = s.acc2 / n; }
     if (kp.stream_mode) {
         // next pixel of this reference thread: x ascending, then y += num_threads (main.cpp:250-251)
         s.px++;
@@ -149,8 +149,8 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     bool term = false;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (is_light) {                                                                    // main.cpp:132-135
-        const double2 e0 = ld2(&m->sexp), e12 = ld2(m->ref + 1);     // (sexp, ref0), (ref1, ref2)
-        c0 = e0.y; c1 = e12.x; c2 = e12.y;
+        const double2 e01 = ld2(m->ref), e2 = ld2(m->ref + 2);       // (ref0, ref1), (ref2, -)
+        c0 = e01.x; c1 = e01.y; c2 = e2.x;
         for (int k = s.nverts - 1; k >= 0; k--) {
             double f0, f1, f2;
             fst.get3(k, f0, f1, f2);
@@ -168,15 +168,15 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         int change = 1;
         double n2 = 1.0;
         bool reflect = false;
-        if (__builtin_fabs(rindex - s.n_cur) < 0.0001) {                               // leaving, main.cpp:158-161
+        // leaving (main.cpp:158-161) and entering by refraction (:168-171) call get_refraction_ray with the same arguments:
+        // one call site serves both (a wave with one glass hit among its lanes pays for it once)
+        const bool leaving = __builtin_fabs(rindex - s.n_cur) < 0.0001;
+        if (!leaving) reflect = rindex == 0.0 || rng_next(s.rng) < 1073741823u;        // main.cpp:164-167: no draw for an opaque solid
+        if (reflect) {
+            fwd = reflection_dir(s.d, normal, gloss_thr, m->inv_sexp, s.rng, &kp.ctrl[1], item);
+        } else {
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
-            change = 0;
-        } else if (rindex == 0.0 || rng_next(s.rng) < 1073741823u) {                   // main.cpp:164-167
-            fwd = reflection_dir(s.d, normal, gloss_thr, m->sexp, s.rng, &kp.ctrl[1], item);
-            reflect = true;
-        } else {                                                                       // main.cpp:168-171
-            fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
-            n2 = rindex;
+            if (leaving) change = 0; else n2 = rindex;
         }
         s.pv_n = normal;
         s.pv_r = dneg(reflect_dir(s.d, normal));

@@ -32,12 +32,14 @@ struct alignas(32) PrimD {   // 96 bytes, indexed by file order: the narrow phas
 // same double operations.
 struct alignas(32) FaceV { double v[3]; double e[3]; double to_next; double pad; };
 
-struct alignas(16) MatD {    // struct Material (geometry.hpp:18-29) in double, 144 bytes
+struct alignas(16) MatD {    // struct Material (geometry.hpp:18-29) in double, 160 bytes
     unsigned is_light;
     unsigned gloss_thr;      // glossy iff rng < gloss_thr  (= ceil(gloss * 2147483646), main.cpp:48)
     double rindex;           // the three above: what a hit decides on, one 16-byte load
     double sexp;
+    double inv_sexp;         // 1 / specular_exp (main.cpp:62), divided once on the host: the same IEEE operation
     double ref[3];
+    double pad;
     double diff[3], spec[3];     // 48 bytes from offset 48
     double rdiff[3], rspec[3];   // 48 bytes from offset 96
 };

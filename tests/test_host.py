@@ -225,3 +225,15 @@ def test_face_bound_holds_every_accepted_point(name):
         assert abs(r - 0.5 * np.hypot(7, 3)) < 1e-4
     if name == "acute_triangle":     # the region is larger than the circle through the vertices allows
         assert far > np.linalg.norm(v - cen, axis=1).max()
+
+
+def test_rng_uniform_reciprocal_division_is_the_ieee_quotient(tmp_path):
+    """The device takes (double)g / 2147483646 (main.cpp:255) as g*y + (g - b*(g*y))*y with y = fl(1/b).  tools/check_rng_div.c
+    compares that with the true division for every possible draw g = 1 .. 2^31 - 2 (a few seconds)."""
+    exe = str(tmp_path / "check_rng_div")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_rng_div.c"), "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bad = 0" in r.stdout, r.stdout
+    # and the constant in the kernel source is that reciprocal
+    assert "0x1.00000004p-31" in r.stdout and "0x1.00000004p-31" in open(os.path.join(PKG, "csrc", "rt_geometry.h")).read()
+    assert float.fromhex("0x1.00000004p-31") == 1.0 / 2147483646.0
