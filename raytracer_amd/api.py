@@ -276,6 +276,8 @@ def expose(rgb: np.ndarray, exposure: float, num_blurs: int) -> np.ndarray:
     mx = 1.0 / exposure
     with np.errstate(invalid="ignore", over="ignore"):
         v = (255 * col / mx)
-        iv = np.where(np.isfinite(v), np.trunc(np.clip(v, -2147483648.0, 2147483647.0)), -2147483648.0).astype(np.int64)
+        # (int)v as the reference's x86 build converts it (cvttsd2si): INT_MIN for NaN and for anything outside int range
+        in_range = np.isfinite(v) & (v > -2147483649.0) & (v < 2147483648.0)
+        iv = np.where(in_range, np.trunc(np.where(in_range, v, 0.0)), -2147483648.0).astype(np.int64)
     iv = np.minimum(iv, 255)
     return ((iv[..., 0] << 16) + (iv[..., 1] << 8) + iv[..., 2]).astype(np.int32)

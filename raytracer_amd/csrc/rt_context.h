@@ -90,6 +90,33 @@ int fail(rt_context* h, int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(h, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// a pair of timing events that every return path destroys; ok() is false when they could not be created
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() { if (hipEventCreate(&a) != hipSuccess) a = nullptr; if (hipEventCreate(&b) != hipSuccess) b = nullptr; }
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    bool ok() const { return a && b; }
+    // milliseconds from a to b, both recorded on the null stream; 0 when anything fails
+    double stop_ms() {
+        float ms = 0;
+        if (!ok() || hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0;
+        return ms;
+    }
+};
+
+// device memory that every return path frees
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) hipFree(p); }
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return (T*)p; }
+};
+
 void free_scene(rt_context* h) {
     hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
     hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux);

@@ -193,9 +193,8 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     if (!params || n_prims < 0 || n_mats < 0 || n_verts < 0 || (n_prims && !prims) || (n_mats && !mats) || (n_verts && !verts))
         return fail(h, RT_ERR_ARG, "rt_upload_scene: null table or negative count");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipEvent_t t0, t1;
-    hipEventCreate(&t0); hipEventCreate(&t1);
-    hipEventRecord(t0, 0);
+    EventPair tm;
+    if (tm.ok()) hipEventRecord(tm.a, 0);
     const int W = (int)params[RT_PA_WIDTH], H = (int)params[RT_PA_HEIGHT];
     const int spp = (int)params[RT_PA_SPP], depth = (int)params[RT_PA_DEPTH];
     if (W < 1 || H < 1 || spp < 1 || depth < 0) return fail(h, RT_ERR_ARG, "rt_upload_scene: width, height, paths_per_pixel must be >= 1, depth >= 0");
@@ -402,6 +401,8 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     const bool grid_ok = build_grid(n_prims, pd, bc, br, always, T, h->grid_density, gh);
 
     free_scene(h);
+    // device tables; a failure part of the way leaves no table behind (have_scene stays false until the end)
+    const int rc_tables = [&]() -> int {
     if (grid_ok) {
         HIP_TRY(h, hipMalloc((void**)&h->d_cells, gh.cells.size() * sizeof(unsigned)));
         HIP_TRY(h, hipMalloc((void**)&h->d_item_rec, gh.item_rec.size() * sizeof(float)));
@@ -427,6 +428,9 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     HIP_TRY(h, hipMemcpy(h->d_prims, pd.data(), pd.size() * sizeof(PrimD), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_verts, vd.data(), vd.size() * sizeof(FaceV), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_mats, md.data(), md.size() * sizeof(MatD), hipMemcpyHostToDevice));
+        return RT_OK;
+    }();
+    if (rc_tables != RT_OK) { free_scene(h); return rc_tables; }
 
     h->width = W; h->height = H; h->spp = spp; h->depth = depth;
     h->num_threads = (int)params[RT_PA_THREADS] > 0 ? (int)params[RT_PA_THREADS] : 1;
@@ -451,12 +455,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     h->cmax = (float)(cmax * (1.0 + 1e-6)) ;
     for (int k = 0; k < 3; k++) h->T[k] = T[k];
     h->have_scene = true;
-    hipEventRecord(t1, 0);
-    hipEventSynchronize(t1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, t0, t1);
-    h->timing.upload_ms = ms;
-    hipEventDestroy(t0); hipEventDestroy(t1);
+    h->timing.upload_ms = tm.stop_ms();
     return RT_OK;
 }
 
@@ -721,9 +720,8 @@ static int render_host(rt_handle h, int stream_mode, double* rgb, uint64_t* rays
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
     if (!rgb) return fail(h, RT_ERR_ARG, "rt_render: rgb is null");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipEvent_t t0, t1;
-    hipEventCreate(&t0); hipEventCreate(&t1);
-    hipEventRecord(t0, 0);
+    EventPair tm;
+    if (tm.ok()) hipEventRecord(tm.a, 0);
     const size_t npx = (size_t)h->width * h->height;
     const size_t rb = npx * 3 * sizeof(double), hb = npx * h->spp * sizeof(int32_t);
     if (h->d_rgb_bytes < rb) { hipFree(h->d_rgb); h->d_rgb = nullptr; h->d_rgb_bytes = 0; HIP_TRY(h, hipMalloc((void**)&h->d_rgb, rb)); h->d_rgb_bytes = rb; }
@@ -733,12 +731,7 @@ static int render_host(rt_handle h, int stream_mode, double* rgb, uint64_t* rays
     rc = rt_finish(h, rays);
     HIP_TRY(h, hipMemcpy(rgb, h->d_rgb, rb, hipMemcpyDeviceToHost));
     if (hit_ids) HIP_TRY(h, hipMemcpy(hit_ids, h->d_hits, hb, hipMemcpyDeviceToHost));
-    hipEventRecord(t1, 0);
-    hipEventSynchronize(t1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, t0, t1);
-    h->timing.total_ms = ms;
-    hipEventDestroy(t0); hipEventDestroy(t1);
+    h->timing.total_ms = tm.stop_ms();
     return rc;
 }
 
@@ -934,18 +927,18 @@ int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* 
     if (!h || n < 0 || !x || !out || fn < 0 || fn > 6) return RT_ERR_ARG;
     if (n == 0) return RT_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    DevMem mx, my, mout;
     size_t b = (size_t)n * sizeof(double);
-    HIP_TRY(h, hipMalloc((void**)&dx, b));
-    HIP_TRY(h, hipMalloc((void**)&dy, b));
-    HIP_TRY(h, hipMalloc((void**)&dout, b));
+    HIP_TRY(h, mx.alloc(b));
+    HIP_TRY(h, my.alloc(b));
+    HIP_TRY(h, mout.alloc(b));
+    double *dx = mx.as<double>(), *dy = my.as<double>(), *dout = mout.as<double>();
     HIP_TRY(h, hipMemcpy(dx, x, b, hipMemcpyHostToDevice));
     if (y) HIP_TRY(h, hipMemcpy(dy, y, b, hipMemcpyHostToDevice));
     else HIP_TRY(h, hipMemset(dy, 0, b));
     hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy, dout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpy(out, dout, b, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dy); hipFree(dout);
     return RT_OK;
 }
 
@@ -961,11 +954,12 @@ int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* d
         const double ext = make_record(centres + 3 * (size_t)i, fabs(radii[i]), &rec[4 * (size_t)i]);
         if (ext > cmax) cmax = ext;
     }
-    double *dO = nullptr, *dD = nullptr; float4* dR = nullptr; int* dF = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&dO, (size_t)n * 24));
-    HIP_TRY(h, hipMalloc((void**)&dD, (size_t)n * 24));
-    HIP_TRY(h, hipMalloc((void**)&dR, (size_t)n * 16));
-    HIP_TRY(h, hipMalloc((void**)&dF, (size_t)n * 4));
+    DevMem mO, mD, mR, mF;
+    HIP_TRY(h, mO.alloc((size_t)n * 24));
+    HIP_TRY(h, mD.alloc((size_t)n * 24));
+    HIP_TRY(h, mR.alloc((size_t)n * 16));
+    HIP_TRY(h, mF.alloc((size_t)n * 4));
+    double *dO = mO.as<double>(), *dD = mD.as<double>(); float4* dR = mR.as<float4>(); int* dF = mF.as<int>();
     HIP_TRY(h, hipMemcpy(dO, origins, (size_t)n * 24, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(dD, dirs, (size_t)n * 24, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(dR, rec.data(), (size_t)n * 16, hipMemcpyHostToDevice));
@@ -973,7 +967,6 @@ int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* d
                        (float)(cmax * (1.0 + 1e-6)), 0.0, 0.0, 0.0, dF);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpy(flags, dF, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(dO); hipFree(dD); hipFree(dR); hipFree(dF);
     return RT_OK;
 }
 

@@ -237,3 +237,16 @@ def test_rng_uniform_reciprocal_division_is_the_ieee_quotient(tmp_path):
     # and the constant in the kernel source is that reciprocal
     assert "0x1.00000004p-31" in r.stdout and "0x1.00000004p-31" in open(os.path.join(PKG, "csrc", "rt_geometry.h")).read()
     assert float.fromhex("0x1.00000004p-31") == 1.0 / 2147483646.0
+
+
+def test_numpy_expose_mirror_converts_like_x86_at_the_edges():
+    """api.expose against the oracle's expose (which follows the reference's cvttsd2si conversion) on the values
+    Color::to_int meets at its edges: out of int range in both directions, infinities, NaN, negative, exact steps."""
+    special = np.array([0.0, -0.0, -0.3, 1.0, np.nextafter(1.0, 0), np.nextafter(1.0, 9), 1e300, -1e300, np.inf, -np.inf, np.nan,
+                        3e9, -3e9, 8421504.5, 8421505.0, -8421505.0, 1e-320, 254.999999 / 255, 2147483647.9 / 255, 2147483648.0 / 255])
+    rgb = np.zeros((5, 8, 3))
+    rgb.reshape(-1)[: special.size] = special
+    rgb.reshape(-1)[special.size: 2 * special.size] = special[::-1]
+    for exposure in (1.0, 0.5, 2.0):
+        want, _ = po.expose(rgb, exposure, 0)
+        assert np.array_equal(api.expose(rgb, exposure, 0), want), exposure
