@@ -11,8 +11,9 @@ the packed rows are gathered to rank 0 (RCCL) and de-interleaved there.  The fra
 so scaling over N is strong scaling.
 
 Prints ONE JSON line on rank 0: Mrays/s (whole job), ms per frame, the FP32-VALU roofline
-figure of the render kernel (algorithmic FLOP of the closest-hit scan / kernel time, HIP
-events on the launch stream) and, at N = 1, the CPU baseline: the reference's own binary
+figures (algorithmic FLOP of the closest-hit scan over the time of all kernels of the frame --
+the headline -- and over broad_kernel's own time; executed FLOP; HIP events on the launch
+stream) and, at N = 1, the CPU baseline: the reference's own binary
 (oracle/_ref, kind "reference") or the oracle port timed on the host cores on a bounded sample.
 """
 from __future__ import annotations
@@ -68,17 +69,24 @@ def cpu_baseline(workload, cores):
             "seconds": secs, "rays": rays}
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per frame of the kernel's launches, from the committed rocprofv3 --pmc passes of this workload
-    (profiles/r1/traffic.json, written by tools/summarize_profile.py); None when no such profile is present."""
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+
+
+def measured_traffic(kernel_prefix, key="bytes_per_frame"):
+    """Per-frame figure of the kernel's launches from the committed rocprofv3 --pmc passes of this workload
+    (profiles/r2/traffic.json, written by tools/summarize_profile.py): HBM bytes, or with key="valu_insts" the
+    SQ_INSTS_VALU count; None when no such profile is present."""
     try:
-        k = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))["kernels"]
+        k = json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["kernels"]
         for name, v in k.items():
             if name.startswith(kernel_prefix):
-                return v["bytes_per_frame"]
+                return v.get(key)
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+EXECUTED_FLOP_PER_TEST = 15     # what broad_kernel executes per (ray, record): 7 fma + 1 sub (+ 1 bit operation, not counted)
 
 
 def main():
@@ -235,7 +243,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_frame / (ms_per_step * 1e-3) / 1e6
-        achieved = flops_local / (broad_ms * 1e-3) / 1e12
+        # Two readings of the same frame.  Headline (frac): the closest-hit scan's ALGORITHMIC FLOP -- every ray against every
+        # solid, 19 per sphere, 12 per plane, 18 + 7 per vertex for a face, as the reference's O(N) loop defines the work --
+        # divided by the time of ALL kernels of the frame.  kernel_*: the same FLOP over broad_kernel's own time.  executed_*:
+        # what broad_kernel really executes, 15 FLOP per (ray, padded record) whatever the solid's kind (it evaluates a
+        # conservative bounding-sphere discriminant; root, epsilon test, closest-hit compare and polygon test run in
+        # shade_kernel in FP64 on the few records it keeps).
+        frame_s = frame_kernels_ms * 1e-3
+        achieved = flops_local / frame_s / 1e12
+        kernel_achieved = flops_local / (broad_ms * 1e-3) / 1e12
+        padded = (len(sc.prims) + 31) // 32 * 32
+        executed = EXECUTED_FLOP_PER_TEST * tm["rays"] * padded / (broad_ms * 1e-3) / 1e12
+        valu = measured_traffic("broad_kernel", "valu_insts") if args.workload == "c3" and args.width is None and world == 1 else None
         cnt = sc.counts()
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -244,16 +263,23 @@ def main():
             "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
+                       "flop_credit": "19 per ray-sphere, 12 per ray-plane, 18 + 7 per vertex per ray-face (46 for a quad), although the FP32 "
+                                      "kernel runs the same 15-FLOP bounding-sphere test for every kind of solid",
                        "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",
                        "step": "render + expose (num_blurs %d%s) + gather" % (blurs, ", bloom on every rank from all-gathered over-exposure bits" if pipe.halo else "")
                                + ("; a frame's gather overlaps the next frame's render" if pipe.pipelined else "")},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                         "basis": "algorithmic FLOP of the closest-hit scan (every ray x every solid) / time of all kernels of the frame",
+                         "kernel_achieved": kernel_achieved, "kernel_frac": kernel_achieved / FP32_VALU_PEAK_TFLOPS,
+                         "executed": executed, "executed_frac": executed / FP32_VALU_PEAK_TFLOPS,
+                         "executed_basis": "15 FLOP x rays x padded records (%d) / broad_kernel time" % padded,
+                         # issue slots used: one VALU wave-instruction per SIMD every 2 cycles at 2.4 GHz is the peak
+                         "valu_issue_frac": (valu / (1024 * 1.2e9 * broad_ms * 1e-3)) if valu else None,
                          "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,
                          "traffic_unit": "HBM bytes per frame (all broad_kernel launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE",
                          "kernel": "broad_kernel (all launches of one frame)", "kernel_ms": broad_ms,
                          "frame_kernels_ms": frame_kernels_ms, "frame_kernels_serial_ms": serial_ms,
-                         "frac_whole_frame": flops_local / (frame_kernels_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
                          "rays_this_gpu": rays_local, "candidates_per_ray": tm["candidates"] / max(1, tm["rays"]),
                          "overflow_rays": tm.get("overflow_rays", 0)},
         }

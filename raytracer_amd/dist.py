@@ -62,8 +62,13 @@ class FrameGatherer:
         if rank == 0:
             self.frame = torch.empty((height, width * channels), dtype=dtype, device=device)
             # every rank's buffer lands in one tensor [world, pad_rows, W*c]; global row y is row src_row[y] of its
-            # flattened view, so the de-interleave is ONE index_select whatever the number of ranks
-            self.recv_all = torch.empty((world, self.pad_rows, width * channels), dtype=dtype, device=device) if world > 1 else None
+            # flattened view, so the de-interleave is ONE index_select whatever the number of ranks.  Two such tensors,
+            # used alternately like the send buffers: the gather of frame i+1 (started before frame i is put in row
+            # order when the caller pipelines) never writes what frame i's index_select still reads, whatever the
+            # backend's stream ordering.
+            self._recv_all = [torch.empty((world, self.pad_rows, width * channels), dtype=dtype, device=device) for _ in range(2)] if world > 1 else None
+            self._recv_cur, self._recv_sent = 0, 0
+            self.recv_all = self._recv_all[0] if world > 1 else None
             self.recv = [self.recv_all[r] for r in range(world)] if world > 1 else None
             y = torch.arange(height, dtype=torch.long)
             tile = y // tile_rows
@@ -86,6 +91,11 @@ class FrameGatherer:
         buf = self.local
         self._sent = buf
         self._work = None
+        if self.world > 1 and self.rank == 0:
+            self._recv_sent = self._recv_cur
+            self.recv_all = self._recv_all[self._recv_cur]
+            self.recv = [self.recv_all[r] for r in range(self.world)]
+            self._recv_cur ^= 1
         if self.world > 1:
             if self.stage:
                 recv = [torch.empty(buf.shape, dtype=self.dtype) for _ in range(self.world)] if self.rank == 0 else None
@@ -108,7 +118,7 @@ class FrameGatherer:
             # one rank owns every tile, in order: its buffer is the frame
             self.frame.copy_(self._sent[: self.h])
         else:
-            torch.index_select(self.recv_all.view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
+            torch.index_select(self._recv_all[self._recv_sent].view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
         return self.frame
 
 

@@ -62,6 +62,9 @@ if st:
     for (k, c), v in sorted(st.items()):
         if 'rocclr' in k or k.startswith('at::'): continue
         lines.append('| %s | %s | %.4g |' % (k, c, v))
+for k in traffic:          # VALU wave-instructions per frame (bench.py: roofline.valu_issue_frac)
+    v = st.get((k, 'SQ_INSTS_VALU'))
+    if v is not None: traffic[k]['valu_insts'] = v
 open(os.path.join(dst, prefix + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
 json.dump({'source': prefix, 'workload': bench.get('config', {}).get('workload'), 'note': 'HBM bytes per frame and kernel: (2 x FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes',
            'kernels': traffic}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
