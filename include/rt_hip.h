@@ -245,6 +245,40 @@ int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* 
 int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* dirs, const double* centres,
                       const double* radii, int32_t* flags);
 
+/* ---- one process, several GPUs ------------------------------------------------------------------------------------------
+ * The reference renders one frame on num_threads threads that share the Color array, thread t taking rows t, t+T, ...
+ * (main.cpp:250,303-313), then exposes and writes it (:314,327).  rt_multi_* is that for the GPUs of one node: rank r =
+ * HIP device r renders the cyclic row tiles k*tile_rows.. with k % n_gpus == r (scene replicated, pixels seeded from their
+ * frame index: the frame does not depend on the partition), exposes and packs its own rows -- with blur passes after an
+ * all-gather of one byte of over-exposure bits per pixel --, and the packed rows (4 bytes per pixel in all) are gathered to
+ * device 0 with RCCL (grouped ncclSend / ncclRecv, one xGMI link per sending device) and put in frame order there.
+ * The RCCL library is loaded when the first context with more than one GPU is created.  One caller at a time per handle. */
+typedef struct rt_multi_context* rt_multi_handle;
+
+/* Contexts on HIP devices 0 .. n_gpus-1 and an RCCL communicator over them (n_gpus <= hipGetDeviceCount).
+ * With RT_MULTI_LOOPBACK=1 in the environment the n_gpus ranks all live on device 0 and exchange rows by device copies:
+ * the whole multi-rank path except the RCCL calls, for tests on a one-GPU machine.
+ * Replaces: the allocation block and thread objects of main(), main.cpp:300-306. */
+int rt_multi_create(rt_multi_handle* out, int n_gpus);
+void rt_multi_destroy(rt_multi_handle m);
+int rt_multi_gpus(rt_multi_handle m);
+/* rt_set_option on every rank's context. */
+int rt_multi_set_option(rt_multi_handle m, int key, int value);
+/* rt_upload_scene on every rank (same arguments). */
+int rt_multi_upload_scene(rt_multi_handle m, const double* params, int n_prims, const double* prims, int n_mats,
+                          const double* mats, int n_verts, const double* verts);
+/* The timed section of main() (main.cpp:304-314) on all ranks: render, expose with the scene header's exposure and
+ * num_blurs, gather, frame order; the packed frame is copied to the host.
+ *   tile_rows : rows per tile of the cyclic partition; 0 = default (8, or one band per rank when there are blur passes)
+ *   img       : int32[height*width], what writeImage takes (pngUtil.c:4);  rays: out, ray segments traced on all ranks */
+int rt_multi_render_image(rt_multi_handle m, int tile_rows, int32_t* img, uint64_t* rays);
+/* Wall-clock milliseconds of the last rt_multi_render_image (enqueue to frame on the host). */
+double rt_multi_last_ms(rt_multi_handle m);
+const char* rt_multi_last_error(rt_multi_handle m);
+/* Host arithmetic of the gather: the row of the gathered buffer [n_gpus][pad_rows][width] that holds frame row y
+ * (pad_rows >= the largest row count of a rank).  No GPU call. */
+int rt_gather_source_row(int height, int tile_rows, int world, int pad_rows, int y);
+
 /* Host-only self-test (no GPU call): the bounding sphere the library gives a face before the FP32 broad phase and the
  * grid may cull it.  Face::intersect (geometry.cpp:160-168) accepts, per vertex, a half-plane bordered by the line through
  * v_i perpendicular to edge i -- the polygon only for rectangles, a larger or unbounded region otherwise -- and the sphere

@@ -29,7 +29,9 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_face_bound")
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_face_bound",
+           "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
+           "rt_multi_render_image", "rt_multi_last_ms", "rt_multi_last_error", "rt_gather_source_row")
 
 
 class RtError(RuntimeError):
@@ -97,6 +99,24 @@ def load_library(path: str = LIB_PATH):
     l.rt_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
     l.rt_selftest_broad.restype = C.c_int
     l.rt_selftest_broad.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+    l.rt_multi_create.restype = C.c_int
+    l.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    l.rt_multi_destroy.restype = None
+    l.rt_multi_destroy.argtypes = [C.c_void_p]
+    l.rt_multi_gpus.restype = C.c_int
+    l.rt_multi_gpus.argtypes = [C.c_void_p]
+    l.rt_multi_set_option.restype = C.c_int
+    l.rt_multi_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    l.rt_multi_upload_scene.restype = C.c_int
+    l.rt_multi_upload_scene.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
+    l.rt_multi_render_image.restype = C.c_int
+    l.rt_multi_render_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    l.rt_multi_last_ms.restype = C.c_double
+    l.rt_multi_last_ms.argtypes = [C.c_void_p]
+    l.rt_multi_last_error.restype = C.c_char_p
+    l.rt_multi_last_error.argtypes = [C.c_void_p]
+    l.rt_gather_source_row.restype = C.c_int
+    l.rt_gather_source_row.argtypes = [C.c_int] * 5
     l.rt_face_bound.restype = C.c_int
     l.rt_face_bound.argtypes = [C.c_int, dp, dp, dp, dp]
     _lib = l
@@ -246,6 +266,57 @@ class Renderer:
         flags = np.zeros(len(r), dtype=np.int32)
         self._check(self.lib.rt_selftest_broad(self.h, len(r), _dp(o), _dp(d), _dp(c), _dp(r), flags.ctypes.data_as(C.POINTER(C.c_int32))))
         return flags
+
+
+class MultiRenderer:
+    """One rt_multi_handle: the GPUs 0..n_gpus-1 of this node in one process, rows gathered to GPU 0 inside the library
+    (RCCL).  With RT_MULTI_LOOPBACK=1 in the environment the ranks all live on GPU 0 (tests on a one-GPU machine)."""
+
+    def __init__(self, n_gpus: int):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.rt_multi_create(C.byref(self.h), int(n_gpus))
+        if rc != RT_OK:
+            raise RtError(rc, f"rt_multi_create({n_gpus}) failed")
+        self.scene = None
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_multi_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.rt_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: int, value: int):
+        self._check(self.lib.rt_multi_set_option(self.h, int(key), int(value)))
+
+    def upload(self, sc: S.Scene):
+        params = sc.params()
+        prims = np.ascontiguousarray(sc.prims, dtype=np.float64)
+        mats = np.ascontiguousarray(sc.mats, dtype=np.float64)
+        verts = np.ascontiguousarray(sc.verts, dtype=np.float64)
+        self._check(self.lib.rt_multi_upload_scene(self.h, _dp(params), len(prims), _dp(prims) if len(prims) else None,
+                                                   len(mats), _dp(mats) if len(mats) else None,
+                                                   len(verts), _dp(verts) if len(verts) else None))
+        self.scene = sc
+
+    def render_image(self, tile_rows: int = 0):
+        """Render + expose + gather: dict(img=int32[H,W], rays=int, ms=wall-clock of the call)."""
+        sc = self.scene
+        if sc is None:
+            raise RtError(-3, "no scene uploaded")
+        img = np.zeros((sc.height, sc.width), dtype=np.int32)
+        rays = C.c_uint64(0)
+        self._check(self.lib.rt_multi_render_image(self.h, int(tile_rows), img.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(rays)))
+        return dict(img=img, rays=int(rays.value), ms=float(self.lib.rt_multi_last_ms(self.h)))
 
 
 # ------------------------------------------------------------------ host post-process

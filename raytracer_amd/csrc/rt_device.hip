@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -971,3 +972,5 @@ int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* d
 }
 
 }  // extern "C"
+
+#include "rt_multi.h"           // rt_multi_*: several GPUs in one process, RCCL gather

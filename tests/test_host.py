@@ -137,7 +137,7 @@ def test_write_image_round_trip(tmp_path):
 
 def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(rt_[a-z_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|double|const char\*)\s+(rt_[a-z_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
     lib = api.load_library()
     for name in declared:
@@ -250,3 +250,20 @@ def test_numpy_expose_mirror_converts_like_x86_at_the_edges():
     for exposure in (1.0, 0.5, 2.0):
         want, _ = po.expose(rgb, exposure, 0)
         assert np.array_equal(api.expose(rgb, exposure, 0), want), exposure
+
+
+def test_gather_source_row_matches_the_partition():
+    """rt_gather_source_row (host arithmetic of the in-library gather) against the packing order of the partition: rank r's
+    buffer holds its rows in ascending order, buffers are stacked by rank with pad_rows rows each."""
+    from raytracer_amd.dist import max_rows, rows_of_rank
+    lib = api.load_library()
+    for (h, t, w) in ((90, 8, 3), (37, 1, 4), (40, 8, 8), (2160, 8, 8), (23, 23, 2), (5, 2, 7)):
+        pad = max_rows(h, t, w)
+        want = np.full(h, -1)
+        for r in range(w):
+            rows = rows_of_rank(h, t, r, w).numpy()
+            want[rows] = r * pad + np.arange(len(rows))
+        got = np.array([lib.rt_gather_source_row(h, t, w, pad, y) for y in range(h)])
+        assert np.array_equal(got, want), (h, t, w)
+        assert sum(lib.rt_rows_for_rank(h, t, r, w) for r in range(w)) == h
+    assert lib.rt_gather_source_row(10, 0, 2, 5, 0) < 0 and lib.rt_gather_source_row(10, 2, 2, 5, 10) < 0
