@@ -286,6 +286,12 @@ int rt_gather_source_row(int height, int tile_rows, int world, int pad_rows, int
  * Returns 1 and (centre[3], radius) when the region is bounded, 0 when the face is tested for every ray, < 0 on error. */
 int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius);
 
+/* Self-test of the broad phase on the matrix cores: every one of n_rays rays against every one of n_rec bounding spheres,
+ * evaluated exactly as broad_mfma_kernel does.  masks: uint32[n_rays * ceil(n_rec / 32)] (HOST); bit 31 - k of
+ * masks[ray * groups + g] is set iff record 32 g + k is kept for the ray. */
+int rt_selftest_broad_mfma(rt_handle h, int n_rays, const double* origins, const double* dirs, int n_rec, const double* centres,
+                           const double* radii, uint32_t* masks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_face_bound",
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
            "rt_multi_render_image", "rt_multi_last_ms", "rt_multi_last_error", "rt_gather_source_row")
 
@@ -99,6 +99,8 @@ def load_library(path: str = LIB_PATH):
     l.rt_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
     l.rt_selftest_broad.restype = C.c_int
     l.rt_selftest_broad.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int32)]
+    l.rt_selftest_broad_mfma.restype = C.c_int
+    l.rt_selftest_broad_mfma.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int, dp, dp, C.POINTER(C.c_uint32)]
     l.rt_multi_create.restype = C.c_int
     l.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     l.rt_multi_destroy.restype = None
@@ -259,6 +261,16 @@ class Renderer:
         code = {"sin": 0, "cos": 1, "acos": 2, "pow": 3, "div": 4, "sqrt": 5, "rng": 6}[fn]
         self._check(self.lib.rt_selftest_math(self.h, code, x.size, _dp(x), _dp(y), _dp(out)))
         return out
+
+    def selftest_broad_mfma(self, origins, dirs, centres, radii):
+        """bool[n_rays, n_rec]: does the matrix-core broad phase keep record j for ray i."""
+        o = np.ascontiguousarray(origins, dtype=np.float64); d = np.ascontiguousarray(dirs, dtype=np.float64)
+        c = np.ascontiguousarray(centres, dtype=np.float64); r = np.ascontiguousarray(radii, dtype=np.float64)
+        groups = (len(r) + 31) // 32
+        masks = np.zeros((len(o), groups), dtype=np.uint32)
+        self._check(self.lib.rt_selftest_broad_mfma(self.h, len(o), _dp(o), _dp(d), len(r), _dp(c), _dp(r), masks.ctypes.data_as(C.POINTER(C.c_uint32))))
+        bits = (masks[:, :, None] >> (31 - np.arange(32, dtype=np.uint32))[None, None, :]) & 1
+        return bits.reshape(len(o), groups * 32)[:, : len(r)].astype(bool)
 
     def selftest_broad(self, origins, dirs, centres, radii):
         o = np.ascontiguousarray(origins, dtype=np.float64); d = np.ascontiguousarray(dirs, dtype=np.float64)

@@ -20,6 +20,13 @@ namespace {
 // A kept sphere is still dropped if it lies wholly behind the origin: hb~ > Eh and oo~ > E0.
 constexpr float BROAD_DELTA = 1.9e-6f;         // used in thr; the applied scale 1.000001^2 - 1 is larger
 constexpr float BROAD_SCALE = 1.000001f;
+// "wide" bounds, for the evaluation on the matrix cores (rt_kernel_mfma.h): the dot products drop partial products of at
+// most 3 * 2^-24 of the largest and are accumulated over up to 32 terms in an order the hardware does not state, each
+// addition rounding by at most u times the running sum <= S (resp. S^2):  Eh = 64 u S,  E0 = 96 u S^2.  delta is chosen
+// near Eh / |hb| for typical rays, which minimises delta hb^2 + Eh^2 / delta.
+constexpr float BROAD_WIDE_EH = 64.0f, BROAD_WIDE_E0 = 96.0f;
+constexpr float BROAD_WIDE_DELTA = 6.0e-6f;    // the applied scale 1.0000035^2 - 1 = 7.0e-6 is larger
+constexpr float BROAD_WIDE_SCALE = 1.0000035f;
 
 struct RayRec {
     float4 a;   // -d' (xyz), od'
@@ -27,17 +34,18 @@ struct RayRec {
     float4 c;   // behind thresholds: hb' > c.x and nq < c.y ; zw unused
 };
 
-DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax) {
+DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = false) {
     RayRec r;
+    const float scale = wide ? BROAD_WIDE_SCALE : BROAD_SCALE, delta = wide ? BROAD_WIDE_DELTA : BROAD_DELTA;
     const float ox = (float)(o.x - T[0]), oy = (float)(o.y - T[1]), oz = (float)(o.z - T[2]);
-    const float fx = (float)d.x * BROAD_SCALE, fy = (float)d.y * BROAD_SCALE, fz = (float)d.z * BROAD_SCALE;
+    const float fx = (float)d.x * scale, fy = (float)d.y * scale, fz = (float)d.z * scale;
     const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
     const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
     const float S = __builtin_sqrtf((float)o2) * 1.0001f + cmax;
-    const float Eh = 14.0f * F32_U * S;
-    const float E0 = 24.0f * F32_U * S * S;
+    const float Eh = (wide ? BROAD_WIDE_EH : 14.0f) * F32_U * S;
+    const float E0 = (wide ? BROAD_WIDE_E0 : 24.0f) * F32_U * S * S;
     r.a = make_float4(-fx, -fy, -fz, (float)od);
-    const double thr = o2 - (double)E0 - (double)Eh * Eh * (1.0 + 1.0 / (double)BROAD_DELTA);
+    const double thr = o2 - (double)E0 - (double)Eh * Eh * (1.0 + 1.0 / (double)delta);
     // rounded down, and strictly below: the pipeline keeps a record iff thr - s is negative
     const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U) - 1e-30f;
     r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);

@@ -25,6 +25,7 @@ struct rt_context {
     void* d_prims = nullptr;
     void* d_verts = nullptr;
     void* d_mats = nullptr;
+    uint4* d_frags = nullptr; int n_groups = 0;   // broad_mfma_kernel: record fragments, 2 KiB per group of 32 records
     void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;
     // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
     uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
@@ -72,6 +73,7 @@ struct rt_context {
     int chunk_records = 8192;  // LDS window in records (16 bytes each)
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    int broad_mfma = 1;        // 1: the broad phase runs on the matrix cores (broad_mfma_kernel), 0: on the vector ALU (broad_kernel)
     bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
     int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
     double grid_density = 1.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY); 0.5 to 8 measured: flat optimum, 1 best on C4
@@ -119,7 +121,8 @@ struct DevMem {
 
 void free_scene(rt_context* h) {
     hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
-    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux);
+    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux); hipFree(h->d_frags);
+    h->d_frags = nullptr; h->n_groups = 0;
     h->d_cells = nullptr; h->d_item_rec = nullptr; h->d_item_aux = nullptr; h->grid_ok = false;
     h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = h->d_always = nullptr;
     h->have_scene = false;
@@ -415,6 +418,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.n_prims = h->n_prims;
     kp.max_verts = RT_MAXV;
     kp.cmax = h->cmax;
+    kp.wide = 0;
     for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
     kp.records = (const float4*)h->d_records;
     kp.chunks = (const ChunkDesc*)h->d_chunks;
@@ -449,6 +453,31 @@ hipError_t launch_broad(rt_context* h, const WfParams& w, unsigned grid, hipStre
     size_t lds = (size_t)h->max_chunk_records * sizeof(float4);
     hipLaunchKernelGGL(broad_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, st, w);
     return hipGetLastError();
+}
+
+// fragment table of broad_mfma_kernel for a padded record stream (n_rec a multiple of 32)
+std::vector<uint4> mf_build_frags(const std::vector<float>& rec) {
+    const size_t groups = rec.size() / 4 / BROAD_GROUP;
+    std::vector<uint4> fr(groups * 128);
+    for (size_t g = 0; g < groups; g++)
+        for (int lane = 0; lane < 64; lane++)
+            mf_record_frags(&rec[g * 4 * BROAD_GROUP], lane, fr[(g * 2 + 0) * 64 + lane], fr[(g * 2 + 1) * 64 + lane]);
+    return fr;
+}
+
+template <int BLOCK>
+hipError_t mfma_grid(rt_context* h, size_t lds, unsigned* grid) {
+    auto kern = broad_mfma_kernel<BLOCK>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = h->grid_mult;
+    if (per_cu <= 0) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+    }
+    *grid = (unsigned)(h->cu_count * per_cu);
+    return hipSuccess;
 }
 
 template <int BLOCK>

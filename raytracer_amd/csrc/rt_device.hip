@@ -53,6 +53,7 @@
 #include "rt_path.h"            // path state, add_to_path segment, narrow phase
 #include "rt_kernel_single.h"   // render_kernel
 #include "rt_kernel_broad.h"    // WfParams, init_kernel, broad_kernel
+#include "rt_kernel_mfma.h"     // broad_mfma_kernel
 #include "rt_kernel_walk.h"     // walk_kernel
 #include "rt_kernel_shade.h"    // find_hit, shade_kernel
 #include "rt_kernel_expose.h"   // expose kernels
@@ -119,6 +120,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_OVERLAP")) rt_set_option(h, RT_OPT_OVERLAP, atoi(e));
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
+    if (const char* e = getenv("RT_BROAD_MFMA")) h->broad_mfma = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
     return RT_OK;
@@ -419,6 +421,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     HIP_TRY(h, hipMalloc(&h->d_always, alw.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_always = n_always; h->always_doubles = always_doubles; h->n_box = n_box;
+    {
+        const std::vector<uint4> fr = mf_build_frags(rec);
+        HIP_TRY(h, hipMalloc((void**)&h->d_frags, fr.size() * sizeof(uint4)));
+        HIP_TRY(h, hipMemcpy(h->d_frags, fr.data(), fr.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        h->n_groups = (int)(fr.size() / 128);
+    }
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));
@@ -562,6 +570,15 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     else e = broad_grid<512>(h, &bgrid);
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
     const bool use_grid = h->accel && h->grid_ok;
+    // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
+    const bool use_mfma = h->broad_mfma && !use_grid && h->d_frags;
+    const size_t mfma_lds = (size_t)(h->n_groups < MF_WINDOW_GROUPS ? h->n_groups : MF_WINDOW_GROUPS) * MF_GROUP_BYTES;
+    unsigned mgrid = 1;
+    if (use_mfma) {
+        e = mfma_grid<512>(h, mfma_lds, &mgrid);
+        if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
+        for (int p = 0; p < nsub; p++) wp[p].kp.wide = 1;
+    }
     unsigned sgrid = (unsigned)h->cu_count * 16u;
     if (const char* e = getenv("RT_SHADE_GRID")) sgrid = (unsigned)h->cu_count * (unsigned)atoi(e);
     h->last_streams = 0;
@@ -613,6 +630,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
                 if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
+                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<512>, dim3(mgrid), dim3(512), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups); e = hipGetLastError(); }
                 else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);
@@ -940,6 +958,42 @@ int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* 
     hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy, dout);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpy(out, dout, b, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_selftest_broad_mfma(rt_handle h, int n_rays, const double* origins, const double* dirs, int n_rec, const double* centres,
+                           const double* radii, uint32_t* masks) {
+    if (!h || n_rays < 0 || n_rec < 0 || !origins || !dirs || !centres || !radii || !masks) return RT_ERR_ARG;
+    if (n_rays == 0 || n_rec == 0) return RT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // records as rt_upload_scene makes them (T = 0, cmax over the batch), padded to whole groups with never-kept records
+    std::vector<float> rec((size_t)n_rec * 4);
+    double cmax = 0;
+    for (int i = 0; i < n_rec; i++) {
+        const double ext = make_record(centres + 3 * (size_t)i, fabs(radii[i]), &rec[4 * (size_t)i]);
+        if (ext > cmax) cmax = ext;
+    }
+    while ((rec.size() / 4) % BROAD_GROUP) { rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(-INFINITY); }
+    const std::vector<uint4> fr = mf_build_frags(rec);
+    const int n_groups = (int)(fr.size() / 128);
+    DevMem mO, mD, mA, mB, mF, mM;
+    HIP_TRY(h, mO.alloc((size_t)n_rays * 24));
+    HIP_TRY(h, mD.alloc((size_t)n_rays * 24));
+    HIP_TRY(h, mA.alloc((size_t)n_rays * 16));
+    HIP_TRY(h, mB.alloc((size_t)n_rays * 16));
+    HIP_TRY(h, mF.alloc(fr.size() * sizeof(uint4)));
+    HIP_TRY(h, mM.alloc((size_t)n_rays * n_groups * 4));
+    HIP_TRY(h, hipMemcpy(mO.p, origins, (size_t)n_rays * 24, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(mD.p, dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(mF.p, fr.data(), fr.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_rayrec_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, 0, n_rays, mO.as<double>(), mD.as<double>(),
+                       (float)(cmax * (1.0 + 1e-6)), 1, mA.as<float4>(), mB.as<float4>());
+    unsigned grid = (unsigned)((n_rays + 31) / 32);
+    if (grid > 4096u) grid = 4096u;
+    hipLaunchKernelGGL(selftest_mfma_kernel, dim3(grid), dim3(64), 0, 0, n_rays, mA.as<float4>(), mB.as<float4>(), mF.as<uint4>(), n_groups,
+                       mM.as<unsigned>());
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpy(masks, mM.p, (size_t)n_rays * n_groups * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -106,7 +106,7 @@ DEV void store_state(const WfParams& w, int q, unsigned pos, const PathState& s)
 DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathState& s, int q) {
     w.queue[q][pos] = slot;
     store_state(w, q, pos, s);
-    const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
+    const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax, w.kp.wide != 0);
     w.rec[0][pos] = r.a; w.rec[1][pos] = r.b;
     w.cand_cnt[(size_t)q * w.slots + pos] = 0u;        // broad_kernel's slices add to it
 }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < w.slots; slot += stride) {
         PathState s;
         start_state(w, slot, s);
-        const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax);
+        const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax, w.kp.wide != 0);
         w.rec[0][slot] = r.a; w.rec[1][slot] = r.b;
         w.cand_cnt[slot] = 0u;
     }

@@ -57,6 +57,7 @@ struct KParams {
     int n_prims;
     int max_verts;           // bounce-stack entries available per path (<= RT_MAXV)
     float cmax;              // max |C - T| + R over finite bounding spheres
+    int wide;                // ray records with the wide error bounds (the broad phase runs on the matrix cores)
     double T[3];             // translation applied before rounding coordinates to float
     const float4* records;
     const ChunkDesc* chunks;

@@ -95,6 +95,42 @@ def test_broad_phase_is_conservative(renderer):
     assert not ((flags == 1) & (disc < -0.5)).any()
 
 
+def test_matrix_core_broad_phase_is_conservative(renderer):
+    """The broad phase on the matrix cores (bf16 pieces, four MFMAs per 32 x 32 pairs): no (ray, sphere) pair with a
+    non-negative exact discriminant may be dropped -- every ray against every sphere of a cloud, plus rays aimed at the
+    silhouettes -- and it must still filter."""
+    rng = np.random.default_rng(11)
+    n_rec, n_rays = 700, 4096                         # not multiples of 32: padded groups and a ragged last ray tile
+    c = rng.uniform(-40, 40, (n_rec, 3))
+    r = rng.uniform(0.05, 3.0, n_rec)
+    o = rng.uniform(-60, 60, (n_rays, 3))
+    # half of the rays graze a chosen sphere, the rest point anywhere
+    pick = rng.integers(0, n_rec, n_rays)
+    tgt = rng.standard_normal((n_rays, 3)); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+    aim = c[pick] + tgt * (r[pick] * rng.uniform(0.95, 1.05, n_rays))[:, None]
+    d = aim - o
+    anyway = rng.random(n_rays) < 0.5
+    d[anyway] = rng.standard_normal((int(anyway.sum()), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    keep = renderer.selftest_broad_mfma(o, d, c, r)
+    assert keep.shape == (n_rays, n_rec)
+    oc = o[:, None, :] - c[None, :, :]
+    hb = (d[:, None, :] * oc).sum(2)
+    disc = hb * hb - ((oc * oc).sum(2) - (r * r)[None, :])
+    dropped = (disc >= 0) & ~keep
+    assert not dropped.any(), f"{int(dropped.sum())} true hits dropped, worst discriminant {disc[dropped].max()}"
+    # margin at these magnitudes (|o| <= 104, |c| <= 70): about 0.1 + 2e-5 |hb|^2 / ... well below 1
+    assert not (keep & (disc < -1.0)).any()
+    assert keep.mean() < 0.02
+    # the grazing rays: the picked sphere is a true hit for about half of them, all kept
+    own = keep[np.arange(n_rays), pick]
+    own_disc = disc[np.arange(n_rays), pick]
+    assert own[(own_disc >= 0)].all() and (own_disc >= 0).sum() > 500
+    # rays that are not of ordinary size keep everything
+    o2 = o[:64].copy(); o2[::2, 0] = 1e30; o2[1::2, 1] = np.nan
+    assert renderer.selftest_broad_mfma(o2, d[:64], c, r).all()
+
+
 def test_scene_json_matches_oracle(renderer, golden_dir):
     sc = S.read_json_scene(os.path.join(golden_dir, "scene.json"))
     g, o = _compare(renderer, sc, "scene.json")
