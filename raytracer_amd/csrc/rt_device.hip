@@ -572,7 +572,10 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     const bool use_grid = h->accel && h->grid_ok;
     // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
     const bool use_mfma = h->broad_mfma && !use_grid && h->d_frags;
-    const size_t mfma_lds = (size_t)(h->n_groups < MF_WINDOW_GROUPS ? h->n_groups : MF_WINDOW_GROUPS) * MF_GROUP_BYTES;
+    // windows of equal size, at most MF_WINDOW_GROUPS groups each
+    const int mf_windows = (h->n_groups + MF_WINDOW_GROUPS - 1) / MF_WINDOW_GROUPS;
+    const int mf_win_groups = mf_windows ? (h->n_groups + mf_windows - 1) / mf_windows : 1;
+    const size_t mfma_lds = (size_t)mf_win_groups * MF_GROUP_BYTES;
     unsigned mgrid = 1;
     if (use_mfma) {
         e = mfma_grid<512>(h, mfma_lds, &mgrid);
@@ -630,7 +633,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
                 if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
-                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<512>, dim3(mgrid), dim3(512), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups); e = hipGetLastError(); }
+                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<512>, dim3(mgrid), dim3(512), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups); e = hipGetLastError(); }
                 else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);

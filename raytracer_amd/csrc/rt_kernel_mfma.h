@@ -22,13 +22,17 @@
 // row that lane half h' reads in register reg, so a lane's 16 sign bits are the keep bits of 16 consecutive records.
 #pragma once
 
+#ifndef MF_USE_SHFL
+#define MF_USE_SHFL 0
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int MF_GROUP_BYTES = 2048;          // two fragments x 64 lanes x 16 bytes per group of 32 records
-constexpr int MF_WINDOW_GROUPS = 32;          // groups per LDS window (64 KiB)
+constexpr int MF_WINDOW_GROUPS = 36;          // most groups per LDS window (72 KiB: two workgroups per CU)
 
 // the three bf16 pieces of a float as 16-bit patterns (truncation: x = h + m + l exactly; a non-finite x keeps only h)
 __host__ __device__ inline void bf16_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -120,18 +124,87 @@ DEV unsigned mf_keep16(const uint4 f0u, const uint4 f1u, const RayFrag& rf) {
 // a ray record of broad_setup that is not of ordinary size carries thr = -inf
 DEV bool mf_ordinary(const float4 rb) { return rb.w > -__builtin_inff(); }
 
-constexpr int MF_TILES = 2;                   // ray tiles (of 32 rays) per wave and batch
+#ifndef MF_TILES_N
+#define MF_TILES_N 2
+#endif
+constexpr int MF_TILES = MF_TILES_N;          // ray tiles (of 32 rays) per wave and batch
+
+// the upper lane half's value in the lower lane half (and the other way round): one v_permlane32_swap
+DEV unsigned mf_other_half(unsigned v) {
+#if MF_USE_SHFL
+    return (unsigned)__shfl_xor((int)v, 32, 64);
+#else
+    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? sw[0] : sw[1];
+#endif
+}
+
+// One workgroup's share of a window: batches of BLOCK/64 x MF_TILES x 32 rays against the groups [g_begin, g_end) staged
+// in LDS.  SLICED: several workgroups scan different groups for the same rays and append through the list's counter;
+// otherwise a ray's list is this lane's alone and its length stays in a register (no memory wait inside the loop).
+template <int BLOCK, bool SLICED>
+DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_cnt, unsigned count, unsigned nbatches,
+                        unsigned batch0, unsigned batch_step, int g0, int g_begin, int g_end, bool first_window) {
+    constexpr unsigned per_block = (BLOCK / 64) * MF_TILES * 32;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    const size_t cstride = w.slots;
+    for (unsigned batch = batch0; batch < nbatches; batch += batch_step) {
+        RayFrag rf[MF_TILES];
+        unsigned pos[MF_TILES], n[MF_TILES];
+        bool own[MF_TILES];
+#pragma unroll
+        for (int t = 0; t < MF_TILES; t++) {
+            pos[t] = batch * per_block + (unsigned)(wv * MF_TILES + t) * 32u + (unsigned)r;
+            const bool valid = pos[t] < count;
+            const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+            const float4 ra = valid ? w.rec[0][pos[t]] : none, rb = valid ? w.rec[1][pos[t]] : none;
+            const bool ordinary = mf_ordinary(rb);
+            rf[t] = mf_ray_frag(ra, rb, h, ordinary);
+            own[t] = valid && h == 0;                 // the lower lane half appends for the ray
+            n[t] = 0;
+            if (own[t]) {
+                if (!ordinary) { n[t] = WF_OVERFLOW; if (SLICED || first_window) cand_cnt[pos[t]] = WF_OVERFLOW; }
+                else if (!first_window) { n[t] = cand_cnt[pos[t]]; if (n[t] > (unsigned)WF_CAND_CAP) n[t] = (unsigned)WF_CAND_CAP + 1u; }
+            }
+            if (!ordinary) own[t] = false;
+        }
+        for (int g = g_begin; g < g_end; g++) {
+            const uint4 f0 = mf_lds[(g * 2 + 0) * 64 + lane], f1 = mf_lds[(g * 2 + 1) * 64 + lane];
+            const unsigned j = (unsigned)(g0 + g);
+#pragma unroll
+            for (int t = 0; t < MF_TILES; t++) {
+                const unsigned mine = mf_keep16(f0, f1, rf[t]);
+                const unsigned other = mf_other_half(mine);
+                const unsigned full = (mine << 16) | other;       // meaningful in the lower lane half
+                if (full != 0u && own[t]) {
+                    if (SLICED) {
+                        const unsigned at = atomicAdd(&cand_cnt[pos[t]], 1u);
+                        if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + pos[t]] = make_uint2(j, full);
+                    } else {
+                        // past the cap the count stops one above it, which is written out as overflow
+                        if (n[t] < (unsigned)WF_CAND_CAP) w.cand[(size_t)n[t] * cstride + pos[t]] = make_uint2(j, full);
+                        n[t] = n[t] < (unsigned)WF_CAND_CAP ? n[t] + 1u : (unsigned)WF_CAND_CAP + 1u;
+                    }
+                }
+            }
+        }
+        if (!SLICED) {
+#pragma unroll
+            for (int t = 0; t < MF_TILES; t++) if (own[t]) cand_cnt[pos[t]] = n[t] > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n[t];
+        }
+    }
+}
 
 // Same contract as broad_kernel: for every queued ray the non-zero 32-record keep masks, appended to its list.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups) {
+__global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups) {
     extern __shared__ uint4 mf_lds[];
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
     constexpr unsigned per_block = (BLOCK / 64) * MF_TILES * 32;
     const unsigned nbatches = (count + per_block - 1) / per_block;
-    const int n_windows = (n_groups + MF_WINDOW_GROUPS - 1) / MF_WINDOW_GROUPS;
+    const int n_windows = (n_groups + win_groups - 1) / win_groups;
     // fewer batches than workgroups: the groups of the (single) window are shared out in slices, see broad_kernel
     unsigned slices = 1;
     if (n_windows == 1 && nbatches < gridDim.x) {
@@ -139,60 +212,18 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, con
         if (slices > (unsigned)n_groups) slices = (unsigned)n_groups;
     }
     if (blockIdx.x >= nbatches * slices) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
-    const size_t cstride = w.slots;
     for (int win = 0; win < n_windows; win++) {
-        const int g0 = win * MF_WINDOW_GROUPS;
-        const int gn = n_groups - g0 < MF_WINDOW_GROUPS ? n_groups - g0 : MF_WINDOW_GROUPS;
+        const int g0 = win * win_groups;
+        const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
         if (win > 0) __syncthreads();
         for (int i = threadIdx.x; i < gn * (MF_GROUP_BYTES / 16); i += BLOCK) mf_lds[i] = frags[(size_t)g0 * (MF_GROUP_BYTES / 16) + i];
         __syncthreads();
-        const unsigned slice = blockIdx.x / nbatches;
-        int g_begin = 0, g_end = gn;
-        if (slices > 1) { g_begin = (int)((unsigned)gn * slice / slices); g_end = (int)((unsigned)gn * (slice + 1) / slices); }
-        for (unsigned batch = slices > 1 ? blockIdx.x % nbatches : blockIdx.x; batch < nbatches; batch += slices > 1 ? nbatches : gridDim.x) {
-            RayFrag rf[MF_TILES];
-            unsigned pos[MF_TILES], n[MF_TILES];
-            bool own[MF_TILES];
-#pragma unroll
-            for (int t = 0; t < MF_TILES; t++) {
-                pos[t] = batch * per_block + (unsigned)(wv * MF_TILES + t) * 32u + (unsigned)r;
-                const bool valid = pos[t] < count;
-                const float4 nan4 = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
-                const float4 ra = valid ? w.rec[0][pos[t]] : nan4, rb = valid ? w.rec[1][pos[t]] : nan4;
-                const bool ordinary = mf_ordinary(rb);
-                rf[t] = mf_ray_frag(ra, rb, h, ordinary);
-                own[t] = valid && h == 0;                 // the lower lane half appends for the ray
-                n[t] = 0;
-                if (own[t]) {
-                    if (!ordinary) { n[t] = WF_OVERFLOW; if (slices > 1 || win == 0) cand_cnt[pos[t]] = WF_OVERFLOW; }
-                    else if (win > 0) n[t] = cand_cnt[pos[t]];
-                }
-                if (!ordinary) own[t] = false;
-            }
-            for (int g = g_begin; g < g_end; g++) {
-                const uint4 f0 = mf_lds[(g * 2 + 0) * 64 + lane], f1 = mf_lds[(g * 2 + 1) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < MF_TILES; t++) {
-                    const unsigned mine = mf_keep16(f0, f1, rf[t]);
-                    const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
-                    const unsigned full = (mine << 16) | other;       // meaningful in the lower lane half
-                    if (full != 0u && own[t]) {
-                        const unsigned j = (unsigned)(g0 + g);
-                        if (slices > 1) {
-                            const unsigned at = atomicAdd(&cand_cnt[pos[t]], 1u);
-                            if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + pos[t]] = make_uint2(j, full);
-                        } else if (n[t] != WF_OVERFLOW) {
-                            if (n[t] < (unsigned)WF_CAND_CAP) { w.cand[(size_t)n[t] * cstride + pos[t]] = make_uint2(j, full); n[t]++; }
-                            else n[t] = WF_OVERFLOW;
-                        }
-                    }
-                }
-            }
-            if (slices == 1) {
-#pragma unroll
-                for (int t = 0; t < MF_TILES; t++) if (own[t]) cand_cnt[pos[t]] = n[t];
-            }
+        if (slices > 1) {
+            const unsigned slice = blockIdx.x / nbatches;
+            mf_scan_window<BLOCK, true>(w, mf_lds, cand_cnt, count, nbatches, blockIdx.x % nbatches, nbatches, g0,
+                                        (int)((unsigned)gn * slice / slices), (int)((unsigned)gn * (slice + 1) / slices), true);
+        } else {
+            mf_scan_window<BLOCK, false>(w, mf_lds, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0);
         }
     }
 }
@@ -210,7 +241,7 @@ __global__ __launch_bounds__(64) void selftest_mfma_kernel(int n_rays, const flo
         for (int g = 0; g < n_groups; g++) {
             const uint4 f0 = frags[(size_t)(g * 2 + 0) * 64 + lane], f1 = frags[(size_t)(g * 2 + 1) * 64 + lane];
             const unsigned mine = mf_keep16(f0, f1, rf);
-            const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
+            const unsigned other = mf_other_half(mine);
             if (valid && h == 0) masks[(size_t)ray * n_groups + g] = ordinary ? ((mine << 16) | other) : 0xffffffffu;
         }
     }
