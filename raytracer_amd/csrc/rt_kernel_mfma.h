@@ -25,6 +25,9 @@
 #ifndef MF_USE_SHFL
 #define MF_USE_SHFL 0
 #endif
+#ifndef MF_PK_FMA
+#define MF_PK_FMA 0
+#endif
 
 namespace {
 
@@ -116,8 +119,19 @@ DEV unsigned mf_keep16(const uint4 f0u, const uint4 f1u, const RayFrag& rf) {
     f32x16 n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.v, rf.q2, zero, 0, 0, 0);
     n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.v, rf.q3, n, 0, 0, 0);
     unsigned m = 0;
+#if MF_PK_FMA
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 x = {hb[i], hb[i + 1]}, y = {n[i], n[i + 1]};
+        const f32x2 t = __builtin_elementwise_fma(-x, x, y);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[0]), 31u);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[1]), 31u);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 16; i++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(__builtin_fmaf(-hb[i], hb[i], n[i])), 31u);
+#endif
     return m;
 }
 
@@ -129,13 +143,14 @@ DEV bool mf_ordinary(const float4 rb) { return rb.w > -__builtin_inff(); }
 #endif
 constexpr int MF_TILES = MF_TILES_N;          // ray tiles (of 32 rays) per wave and batch
 
-// the upper lane half's value in the lower lane half (and the other way round): one v_permlane32_swap
-DEV unsigned mf_other_half(unsigned v) {
+// For a lane of the lower half: the value of its partner lane (lane + 32).  v_permlane32_swap exchanges the upper half
+// of its first operand with the lower half of its second, so with both operands = v the second comes back holding the
+// upper half's values in the lower lanes.  (Lanes of the upper half get their own value back.)
+DEV unsigned mf_from_upper_half(unsigned v) {
 #if MF_USE_SHFL
     return (unsigned)__shfl_xor((int)v, 32, 64);
 #else
-    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return (threadIdx.x & 32) ? sw[0] : sw[1];
+    return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1];
 #endif
 }
 
@@ -151,6 +166,7 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
     for (unsigned batch = batch0; batch < nbatches; batch += batch_step) {
         RayFrag rf[MF_TILES];
         unsigned pos[MF_TILES], n[MF_TILES];
+        uint2* out[MF_TILES];                         // where this ray's next list entry goes (unsliced scan)
         bool own[MF_TILES];
 #pragma unroll
         for (int t = 0; t < MF_TILES; t++) {
@@ -163,10 +179,11 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
             own[t] = valid && h == 0;                 // the lower lane half appends for the ray
             n[t] = 0;
             if (own[t]) {
-                if (!ordinary) { n[t] = WF_OVERFLOW; if (SLICED || first_window) cand_cnt[pos[t]] = WF_OVERFLOW; }
+                if (!ordinary) { if (SLICED || first_window) cand_cnt[pos[t]] = WF_OVERFLOW; }
                 else if (!first_window) { n[t] = cand_cnt[pos[t]]; if (n[t] > (unsigned)WF_CAND_CAP) n[t] = (unsigned)WF_CAND_CAP + 1u; }
             }
             if (!ordinary) own[t] = false;
+            out[t] = w.cand + ((size_t)n[t] * cstride + pos[t]);      // not used by a lane that does not own a ray
         }
         for (int g = g_begin; g < g_end; g++) {
             const uint4 f0 = mf_lds[(g * 2 + 0) * 64 + lane], f1 = mf_lds[(g * 2 + 1) * 64 + lane];
@@ -174,16 +191,17 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
 #pragma unroll
             for (int t = 0; t < MF_TILES; t++) {
                 const unsigned mine = mf_keep16(f0, f1, rf[t]);
-                const unsigned other = mf_other_half(mine);
+                const unsigned other = mf_from_upper_half(mine);
                 const unsigned full = (mine << 16) | other;       // meaningful in the lower lane half
                 if (full != 0u && own[t]) {
                     if (SLICED) {
                         const unsigned at = atomicAdd(&cand_cnt[pos[t]], 1u);
                         if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + pos[t]] = make_uint2(j, full);
                     } else {
-                        // past the cap the count stops one above it, which is written out as overflow
-                        if (n[t] < (unsigned)WF_CAND_CAP) w.cand[(size_t)n[t] * cstride + pos[t]] = make_uint2(j, full);
-                        n[t] = n[t] < (unsigned)WF_CAND_CAP ? n[t] + 1u : (unsigned)WF_CAND_CAP + 1u;
+                        // past the cap the list only counts on; such a count is written out as overflow
+                        if (n[t] < (unsigned)WF_CAND_CAP) *out[t] = make_uint2(j, full);
+                        out[t] += cstride;
+                        n[t]++;                            // at most one per group of the stream on top of CAP + 1: no wrap
                     }
                 }
             }
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(64) void selftest_mfma_kernel(int n_rays, const flo
         for (int g = 0; g < n_groups; g++) {
             const uint4 f0 = frags[(size_t)(g * 2 + 0) * 64 + lane], f1 = frags[(size_t)(g * 2 + 1) * 64 + lane];
             const unsigned mine = mf_keep16(f0, f1, rf);
-            const unsigned other = mf_other_half(mine);
+            const unsigned other = mf_from_upper_half(mine);
             if (valid && h == 0) masks[(size_t)ray * n_groups + g] = ordinary ? ((mine << 16) | other) : 0xffffffffu;
         }
     }
