@@ -578,7 +578,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     const size_t mfma_lds = (size_t)mf_win_groups * MF_GROUP_BYTES;
     unsigned mgrid = 1;
     if (use_mfma) {
-        e = mfma_grid<512>(h, mfma_lds, &mgrid);
+        e = mfma_grid<MF_BLOCK>(h, mfma_lds, &mgrid);
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
         for (int p = 0; p < nsub; p++) wp[p].kp.wide = 1;
     }
@@ -633,7 +633,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
                 if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
-                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<512>, dim3(mgrid), dim3(512), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups); e = hipGetLastError(); }
+                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<MF_BLOCK>, dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups); e = hipGetLastError(); }
                 else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);

@@ -28,12 +28,16 @@
 #ifndef MF_PK_FMA
 #define MF_PK_FMA 0
 #endif
+#ifndef MF_BLOCK_N
+#define MF_BLOCK_N 512
+#endif
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+constexpr int MF_BLOCK = MF_BLOCK_N;           // threads per workgroup of broad_mfma_kernel
 constexpr int MF_GROUP_BYTES = 2048;          // two fragments x 64 lanes x 16 bytes per group of 32 records
 constexpr int MF_WINDOW_GROUPS = 36;          // most groups per LDS window (72 KiB: two workgroups per CU)
 
