@@ -12,8 +12,8 @@ so scaling over N is strong scaling.
 
 Prints ONE JSON line on rank 0: Mrays/s (whole job), ms per frame, the FP32-VALU roofline
 figures (algorithmic FLOP of the closest-hit scan over the time of all kernels of the frame --
-the headline -- and over broad_kernel's own time; executed FLOP; HIP events on the launch
-stream) and, at N = 1, the CPU baseline: the reference's own binary
+the headline -- and over the broad-phase kernel's own time; executed FLOP; HIP events on the
+launch stream) and, at N = 1, the CPU baseline: the reference's own binary
 (oracle/_ref, kind "reference") or the oracle port timed on the host cores on a bounded sample.
 """
 from __future__ import annotations
@@ -87,6 +87,11 @@ def measured_traffic(kernel_prefix, key="bytes_per_frame"):
 
 
 EXECUTED_FLOP_PER_TEST = 15     # what broad_kernel executes per (ray, record): 7 fma + 1 sub (+ 1 bit operation, not counted)
+# broad_mfma_kernel (the default): four v_mfma_f32_32x32x16_bf16 (32*32*16*2 FLOP each) per 32 rays x 32 records, and on
+# the vector ALU one fma per pair (+ 1 bit operation, not counted)
+MFMA_FLOP_PER_TEST = 4 * 32 * 32 * 16 * 2 // 1024
+MFMA_VALU_FLOP_PER_TEST = 2
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16
 
 
 def main():
@@ -245,26 +250,39 @@ def main():
         value = rays_frame / (ms_per_step * 1e-3) / 1e6
         # Two readings of the same frame.  Headline (frac): the closest-hit scan's ALGORITHMIC FLOP -- every ray against every
         # solid, 19 per sphere, 12 per plane, 18 + 7 per vertex for a face, as the reference's O(N) loop defines the work --
-        # divided by the time of ALL kernels of the frame.  kernel_*: the same FLOP over broad_kernel's own time.  executed_*:
-        # what broad_kernel really executes, 15 FLOP per (ray, padded record) whatever the solid's kind (it evaluates a
-        # conservative bounding-sphere discriminant; root, epsilon test, closest-hit compare and polygon test run in
-        # shade_kernel in FP64 on the few records it keeps).
+        # divided by the time of ALL kernels of the frame.  kernel_*: the same FLOP over the broad-phase kernel's own time.
+        # executed_*: what that kernel really executes per (ray, padded record) whatever the solid's kind (it evaluates a
+        # conservative bounding-sphere discriminant -- on the matrix cores by default, 15 FP32 FLOP on the vector ALU with
+        # RT_BROAD_MFMA=0; root, epsilon test, closest-hit compare and polygon test run in shade_kernel in FP64 on the few
+        # records it keeps).
         frame_s = frame_kernels_ms * 1e-3
         achieved = flops_local / frame_s / 1e12
         kernel_achieved = flops_local / (broad_ms * 1e-3) / 1e12
         padded = (len(sc.prims) + 31) // 32 * 32
-        executed = EXECUTED_FLOP_PER_TEST * tm["rays"] * padded / (broad_ms * 1e-3) / 1e12
-        valu = measured_traffic("broad_kernel", "valu_insts") if args.workload == "c3" and args.width is None and world == 1 else None
+        on_mfma = os.environ.get("RT_BROAD_MFMA", "1") != "0"       # the library's default: the scan on the matrix cores
+        kname = "broad_mfma_kernel" if on_mfma else "broad_kernel"
+        pairs = tm["rays"] * padded
+        if on_mfma:
+            executed = MFMA_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
+            executed_peak = BF16_MFMA_PEAK_TFLOPS
+            executed_basis = ("%d bf16 MFMA FLOP x rays x padded records (%d) / %s time, against the dense bf16 MFMA peak; beside it "
+                              "%d FP32 FLOP per pair on the vector ALU" % (MFMA_FLOP_PER_TEST, padded, kname, MFMA_VALU_FLOP_PER_TEST))
+        else:
+            executed = EXECUTED_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
+            executed_peak = FP32_VALU_PEAK_TFLOPS
+            executed_basis = "15 FLOP x rays x padded records (%d) / broad_kernel time" % padded
+        profiled = args.workload == "c3" and args.width is None and world == 1
+        valu = measured_traffic(kname, "valu_insts") if profiled else None
         cnt = sc.counts()
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32 broad phase + f64 exact phase", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("bf16x3 MFMA + f32 broad phase" if on_mfma else "f32 broad phase") + " + f64 exact phase", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
                        "flop_credit": "19 per ray-sphere, 12 per ray-plane, 18 + 7 per vertex per ray-face (46 for a quad), although the FP32 "
-                                      "kernel runs the same 15-FLOP bounding-sphere test for every kind of solid",
+                                      "broad phase runs the same bounding-sphere test for every kind of solid",
                        "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",
                        "step": "render + expose (num_blurs %d%s) + gather" % (blurs, ", bloom on every rank from all-gathered over-exposure bits" if pipe.halo else "")
                                + ("; a frame's gather overlaps the next frame's render" if pipe.pipelined else "")},
@@ -272,13 +290,14 @@ def main():
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                          "basis": "algorithmic FLOP of the closest-hit scan (every ray x every solid) / time of all kernels of the frame",
                          "kernel_achieved": kernel_achieved, "kernel_frac": kernel_achieved / FP32_VALU_PEAK_TFLOPS,
-                         "executed": executed, "executed_frac": executed / FP32_VALU_PEAK_TFLOPS,
-                         "executed_basis": "15 FLOP x rays x padded records (%d) / broad_kernel time" % padded,
+                         "executed": executed, "executed_peak": executed_peak, "executed_frac": executed / executed_peak,
+                         "executed_basis": executed_basis,
                          # issue slots used: one VALU wave-instruction per SIMD every 2 cycles at 2.4 GHz is the peak
+                         # (SQ_INSTS_VALU of the committed counter pass; it includes the MFMA instructions)
                          "valu_issue_frac": (valu / (1024 * 1.2e9 * broad_ms * 1e-3)) if valu else None,
-                         "traffic": measured_traffic("broad_kernel") if args.workload == "c3" and args.width is None and world == 1 else None,
-                         "traffic_unit": "HBM bytes per frame (all broad_kernel launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE",
-                         "kernel": "broad_kernel (all launches of one frame)", "kernel_ms": broad_ms,
+                         "traffic": measured_traffic(kname) if profiled else None,
+                         "traffic_unit": "HBM bytes per frame (all %s launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE" % kname,
+                         "kernel": "%s (all launches of one frame)" % kname, "kernel_ms": broad_ms,
                          "frame_kernels_ms": frame_kernels_ms, "frame_kernels_serial_ms": serial_ms,
                          "rays_this_gpu": rays_local, "candidates_per_ray": tm["candidates"] / max(1, tm["rays"]),
                          "overflow_rays": tm.get("overflow_rays", 0)},

@@ -37,7 +37,27 @@ struct RayRec {
 DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = false) {
     RayRec r;
     const float scale = wide ? BROAD_WIDE_SCALE : BROAD_SCALE, delta = wide ? BROAD_WIDE_DELTA : BROAD_DELTA;
-    const float ox = (float)(o.x - T[0]), oy = (float)(o.y - T[1]), oz = (float)(o.z - T[2]);
+    double px = o.x - T[0], py = o.y - T[1], pz = o.z - T[2];
+    bool far = false;
+    if (wide) {
+        // The matrix-core test looks at the ray's whole line and has no use for the origin as such, so the origin is
+        // moved along the line to the point nearest the scene's centre: |o| and with it the error bounds shrink, and the
+        // constants of a ray that starts far outside the scene (a bounce off the floor plane a long way out) stay inside the
+        // f16 range.  The move is done in double; what it adds to the line's position, a few 2^-53 |o|, is covered by the
+        // slack of Eh while |o| stays below 2^20 scene radii -- beyond that the ray is handed over as not ordinary.
+        // Every record lies within cmax of the centre: a line further out than 2 cmax misses them all and may be
+        // replaced by any other such line (the one at 2 cmax: same keep bits, ordinary magnitudes).
+        const double lim = 1048576.0 * ((double)cmax + 1.0);
+        far = !(__builtin_fabs(px) < lim) | !(__builtin_fabs(py) < lim) | !(__builtin_fabs(pz) < lim);
+        const double dd = d.x * d.x + d.y * d.y + d.z * d.z;
+        if (!far && dd > 1e-300 && dd < 1e300) {
+            const double t = -(px * d.x + py * d.y + pz * d.z) / dd;
+            px += t * d.x; py += t * d.y; pz += t * d.z;
+            const double D2 = px * px + py * py + pz * pz, out = 2.0 * (double)cmax;
+            if (D2 > out * out) { const double k = out / __builtin_sqrt(D2); px *= k; py *= k; pz *= k; }
+        }
+    }
+    const float ox = (float)px, oy = (float)py, oz = (float)pz;
     const float fx = (float)d.x * scale, fy = (float)d.y * scale, fz = (float)d.z * scale;
     const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
     const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
@@ -56,7 +76,7 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = fals
     // is kept and none is "behind": s = the record's own fourth word, thr = -inf.  The exact test then sees every solid.
     const float lim = 1e15f;
     const bool ordinary = (__builtin_fabsf(ox) < lim) & (__builtin_fabsf(oy) < lim) & (__builtin_fabsf(oz) < lim) &
-                          (__builtin_fabsf(fx) < lim) & (__builtin_fabsf(fy) < lim) & (__builtin_fabsf(fz) < lim);
+                          (__builtin_fabsf(fx) < lim) & (__builtin_fabsf(fy) < lim) & (__builtin_fabsf(fz) < lim) & !far;
     if (!ordinary) {
         r.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         r.b = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());

@@ -25,7 +25,8 @@ struct rt_context {
     void* d_prims = nullptr;
     void* d_verts = nullptr;
     void* d_mats = nullptr;
-    uint4* d_frags = nullptr; int n_groups = 0;   // broad_mfma_kernel: record fragments, 2 KiB per group of 32 records
+    uint4* d_frags = nullptr; int n_groups = 0;   // broad_mfma_kernel: record fragments, 1 KiB per group of 32 records
+    float mf_scale = 1.0f;                        //   and the power of two by which its lengths are scaled
     void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;
     // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
     uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
@@ -455,13 +456,12 @@ hipError_t launch_broad(rt_context* h, const WfParams& w, unsigned grid, hipStre
     return hipGetLastError();
 }
 
-// fragment table of broad_mfma_kernel for a padded record stream (n_rec a multiple of 32)
-std::vector<uint4> mf_build_frags(const std::vector<float>& rec) {
+// fragment table of broad_mfma_kernel for a padded record stream (n_rec a multiple of 32), lengths scaled by s
+std::vector<uint4> mf_build_frags(const std::vector<float>& rec, float s) {
     const size_t groups = rec.size() / 4 / BROAD_GROUP;
-    std::vector<uint4> fr(groups * 128);
+    std::vector<uint4> fr(groups * MF_GROUP_WORDS);
     for (size_t g = 0; g < groups; g++)
-        for (int lane = 0; lane < 64; lane++)
-            mf_record_frags(&rec[g * 4 * BROAD_GROUP], lane, fr[(g * 2 + 0) * 64 + lane], fr[(g * 2 + 1) * 64 + lane]);
+        for (int lane = 0; lane < 64; lane++) fr[g * MF_GROUP_WORDS + lane] = mf_record_frag(&rec[g * 4 * BROAD_GROUP], lane, s);
     return fr;
 }
 

@@ -422,10 +422,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_always = n_always; h->always_doubles = always_doubles; h->n_box = n_box;
     {
-        const std::vector<uint4> fr = mf_build_frags(rec);
+        const float mf_scale = mf_scale_for((float)(cmax * (1.0 + 1e-6)));
+        const std::vector<uint4> fr = mf_build_frags(rec, mf_scale);
         HIP_TRY(h, hipMalloc((void**)&h->d_frags, fr.size() * sizeof(uint4)));
         HIP_TRY(h, hipMemcpy(h->d_frags, fr.data(), fr.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        h->n_groups = (int)(fr.size() / 128);
+        h->n_groups = (int)(fr.size() / MF_GROUP_WORDS);
+        h->mf_scale = mf_scale;
     }
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
@@ -633,7 +635,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
                 if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
-                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<MF_BLOCK>, dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups); e = hipGetLastError(); }
+                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<MF_BLOCK>, dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale); e = hipGetLastError(); }
                 else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);
@@ -977,8 +979,9 @@ int rt_selftest_broad_mfma(rt_handle h, int n_rays, const double* origins, const
         if (ext > cmax) cmax = ext;
     }
     while ((rec.size() / 4) % BROAD_GROUP) { rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(0.0f); rec.push_back(-INFINITY); }
-    const std::vector<uint4> fr = mf_build_frags(rec);
-    const int n_groups = (int)(fr.size() / 128);
+    const float scale = mf_scale_for((float)(cmax * (1.0 + 1e-6)));
+    const std::vector<uint4> fr = mf_build_frags(rec, scale);
+    const int n_groups = (int)(fr.size() / MF_GROUP_WORDS);
     DevMem mO, mD, mA, mB, mF, mM;
     HIP_TRY(h, mO.alloc((size_t)n_rays * 24));
     HIP_TRY(h, mD.alloc((size_t)n_rays * 24));
@@ -994,7 +997,7 @@ int rt_selftest_broad_mfma(rt_handle h, int n_rays, const double* origins, const
     unsigned grid = (unsigned)((n_rays + 31) / 32);
     if (grid > 4096u) grid = 4096u;
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(grid), dim3(64), 0, 0, n_rays, mA.as<float4>(), mB.as<float4>(), mF.as<uint4>(), n_groups,
-                       mM.as<unsigned>());
+                       scale, mM.as<unsigned>());
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpy(masks, mM.p, (size_t)n_rays * n_groups * 4, hipMemcpyDeviceToHost));
     return RT_OK;

@@ -2,22 +2,30 @@
 // A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
 //
 // broad_kernel spends 6 of its 9 vector instructions per (ray, record) pair on two dot products, hb = a.c + od and
-// nq = b.c + w.  A dot product of 32 rays with 32 records is a 32x32 matrix product, and v_mfma_f32_32x32x16_bf16 does
-// one with k = 16 in 32 cycles on a pipe of its own.  bf16 keeps 8 significant bits, so every float is cut into three
-// bf16 pieces x = xh + xm + xl (by truncation: the pieces are exact and their sum is x bit for bit) and the product
-// a c = (ah + am + al)(ch + cm + cl) is taken as the six partial products down to 2^-16 of the largest,
-//     ah ch + ah cm + am ch + ah cl + al ch + am cm        (dropped: am cl + al cm + al cl <= 3 * 2^-24 |a c|),
-// each exact in the f32 accumulator.  Four MFMAs per 32 x 32 pairs (two for hb, two for thr - nq, k slots below) leave the
-// vector ALU two instructions per pair -- t = thr - nq - hb^2 by one fma, its sign into the keep mask by one alignbit --
+// nq = b.c + w.  A dot product of 32 rays with 32 records is a 32x32 matrix product, and v_mfma_f32_32x32x16_f16 does
+// one with k = 16 in 32 cycles.  f16 keeps 11 significant bits, so every float is cut into two f16 pieces x = xh + xl
+// (+ a remainder below 2^-21 |x|), and the product a c is taken as the four partial products
+//     ah ch + ah cl + al ch + al cl        (dropped: the remainders, at most 2^-20 |a c|),
+// each exact in the f32 accumulator.  Two MFMAs per 32 x 32 pairs (one for hb, one for N = thr - nq, k slots below) leave
+// the vector ALU two instructions per pair -- t = N - hb^2 by one fma, its sign into the keep mask by one alignbit --
 // instead of nine.  The result is used exactly like broad_kernel's: a conservative filter in front of the exact test.
-// The error bounds Eh, E0 of broad_setup are widened for the dropped products and for an accumulation of up to 32 terms
-// in unspecified order (BROAD_WIDE_*).
+//
+// Range: f16 ends at 65504 and has a fixed absolute resolution of 2^-24 below 2^-14 (subnormals, which the conversions
+// and the MFMA keep: measured).  All lengths are therefore scaled by a power of two s (exact in float) chosen from the
+// scene so that the largest record coordinate lands near 64: squares stay below 2^12, low pieces stay far above 2^-24.
+// A ray whose scaled constants leave the range (origin further than about four scene radii from the scene's centre) is
+// not "ordinary": its list is marked as overflowed and the exact test sees every solid.
+//
+// Error bounds (u = 2^-24, S = |o| + cmax as in broad_setup): hb drops at most 2^-20 |a||c| + 2^-21 |od| <= 24 u S and
+// rounds at most 16 additions of terms bounded by S: below Eh = 64 u S.  nq drops at most 2^-20 * 2|o||c| <= 8 u S^2 and
+// rounds 16 additions: below E0 = 96 u S^2.  thr and w have no room for a third piece; their two pieces are rounded in
+// the direction that keeps more (thr down, w up), which widens the test by at most 2^-21 of each and drops nothing.
 //
 // k slots (lane half h = lane >> 5 supplies k = 8h .. 8h+7 of both operands; c = record centre, w = its fourth word,
-// a = -d', od, nb = -2o, thr = the ray constants of broad_setup):
-//   record fragment F0: h=0 [ch 1 | cm 1]    h=1 [ch 1 | cl 0]          F1: h=0 [ch wh | cm wm]   h=1 [ch wl | cl 1]
-//   hb   = F0 x [ah odh | ah odm],[am odl | ah 0]   +  F0 x [al 0 | am 0],[0]
-//   N    = F1 x [nbh -1 | nbh -1],[nbm -1 | nbh thh]  +  F0 x [nbl thm | nbm thl],[0]          (N = thr - nq)
+// a = -d', od, nb = -2o, thr = the ray constants of broad_setup; everything scaled):
+//   record fragment F:   h=0 [ch 1 | cl 1]         h=1 [ch wh | cl wl]
+//   hb = F x q0,  q0:    h=0 [ah odh | ah odl]     h=1 [al 0  | al 0 ]
+//   N  = F x q1,  q1:    h=0 [nbh thh | nbh thl]   h=1 [nbl -1 | nbl -1]
 // Output tile: column = ray (lane & 31), row = (reg & 3) + 8 (reg >> 2) + 4 h.  Record 16 h' + reg of a group sits in the
 // row that lane half h' reads in register reg, so a lane's 16 sign bits are the keep bits of 16 consecutive records.
 #pragma once
@@ -25,8 +33,8 @@
 #ifndef MF_USE_SHFL
 #define MF_USE_SHFL 0
 #endif
-#ifndef MF_PK_FMA
-#define MF_PK_FMA 0
+#ifndef MF_PIPE
+#define MF_PIPE 0
 #endif
 #ifndef MF_BLOCK_N
 #define MF_BLOCK_N 512
@@ -34,113 +42,162 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int MF_BLOCK = MF_BLOCK_N;           // threads per workgroup of broad_mfma_kernel
-constexpr int MF_GROUP_BYTES = 2048;          // two fragments x 64 lanes x 16 bytes per group of 32 records
-constexpr int MF_WINDOW_GROUPS = 36;          // most groups per LDS window (72 KiB: two workgroups per CU)
+constexpr int MF_GROUP_BYTES = 1024;          // one fragment x 64 lanes x 16 bytes per group of 32 records
+constexpr int MF_GROUP_WORDS = MF_GROUP_BYTES / 16;
+constexpr int MF_WINDOW_GROUPS = 64;          // most groups per LDS window (64 KiB: two workgroups per CU)
+#ifndef MF_RANGE_V
+#define MF_RANGE_V 60000.0f
+#endif
+constexpr float MF_RANGE = MF_RANGE_V;          // scaled ray constants must stay below this (f16 ends at 65504)
 
-// the three bf16 pieces of a float as 16-bit patterns (truncation: x = h + m + l exactly; a non-finite x keeps only h)
-__host__ __device__ inline void bf16_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    union { float f; unsigned u; } a, b, c;
+// ---- host side: the pieces of the records -------------------------------------------------------
+// x cut to the f16 grid towards zero (11 significant bits; multiples of 2^-24 below 2^-14): exact float arithmetic
+inline float f16_trunc(float x) {
+    union { float f; unsigned u; } a;
     a.f = x;
-    const unsigned hu = a.u & 0xffff0000u;
-    h = hu >> 16;
-    if ((a.u & 0x7f800000u) == 0x7f800000u) { m = 0; l = 0; return; }
-    a.u = hu;
-    b.f = x - a.f;                             // exact: at most 16 significant bits are left
-    const unsigned mu = b.u & 0xffff0000u;
-    m = mu >> 16;
-    a.u = mu;
-    c.f = b.f - a.f;                           // exact: at most 8 bits left, a bf16 value
-    l = c.u >> 16;
+    const unsigned e = (a.u >> 23) & 0xffu;
+    if (e == 0xffu) return x;
+    if (e >= 127u - 14u) { a.u &= 0xffffe000u; return a.f; }
+    return truncf(x * 16777216.0f) * (1.0f / 16777216.0f);
+}
+// bit pattern of a float that lies on the f16 grid (or is infinite)
+inline unsigned f16_bits(float v) {
+    union { float f; unsigned u; } a;
+    a.f = v;
+    const unsigned sign = (a.u >> 16) & 0x8000u, e = (a.u >> 23) & 0xffu, man = a.u & 0x7fffffu;
+    if (e == 0xffu) return sign | 0x7c00u | (man ? 0x200u : 0u);
+    if (e == 0u) return sign;
+    const int E = (int)e - 127;
+    if (E > 15) return sign | 0x7c00u;
+    if (E >= -14) return sign | ((unsigned)(E + 15) << 10) | (man >> 13);
+    const int shift = -14 - E;
+    return shift > 11 ? sign : sign | (((0x800000u | man) >> 13) >> shift);
+}
+inline float f16_value(unsigned b) {
+    const int e = (int)((b >> 10) & 0x1fu);
+    const float m = (float)(b & 0x3ffu);
+    float v = e == 0 ? ldexpf(m, -24) : (e == 31 ? INFINITY : ldexpf(1024.0f + m, e - 25));
+    return (b & 0x8000u) ? -v : v;
+}
+// two f16 pieces of x, cut towards zero; up = true: the second piece is raised by one step if the sum fell short of x,
+// so that h + l >= x (h + l - x below 2^-21 |x|)
+inline void f16_split2(float x, bool up, unsigned& h, unsigned& l) {
+    const float xh = f16_trunc(x);
+    h = f16_bits(xh);
+    if (!(fabsf(x) <= 3.0e38f)) { l = 0; return; }     // infinite (a padding record's fourth word) or NaN: the first piece says it all
+    const float r = x - xh;                            // exact
+    float xl = f16_trunc(r);
+    l = f16_bits(xl);
+    if (up && xl < r) {
+        l = (l & 0x8000u) ? (l == 0x8000u ? 0x0001u : l - 1u) : l + 1u;      // next value of the f16 grid above xl
+        xl = f16_value(l);
+    }
 }
 
-union Bf16Pack { uint4 u; bf16x8 v; };
+// the power of two by which lengths are scaled: the largest record extent (|c| + R) lands in (32, 64]
+inline float mf_scale_for(float cmax) {
+    if (!(cmax > 0.0f) || !(cmax < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(cmax, &e);                                  // cmax = m 2^e, m in [0.5, 1)
+    int k = 6 - e;
+    if (k > 100) k = 100;
+    if (k < -100) k = -100;
+    return ldexpf(1.0f, k);
+}
+
 __host__ __device__ inline uint4 pack8(unsigned e0, unsigned e1, unsigned e2, unsigned e3, unsigned e4, unsigned e5, unsigned e6, unsigned e7) {
     return make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
 }
-constexpr unsigned BF16_ONE = 0x3f80u, BF16_MINUS_ONE = 0xbf80u;
+constexpr unsigned F16_ONE = 0x3c00u, F16_MINUS_ONE = 0xbc00u;
 
 // the row of the output tile (= row of the record operand) in which record k of a group is placed
 __host__ __device__ inline int mf_row_of_record(int k) { const int hp = k >> 4, reg = k & 15; return (reg & 3) + 8 * (reg >> 2) + 4 * hp; }
 
-// the two fragments of lane `lane` for one group of 32 records (rec: 32 x float4 in stream order)
-__host__ __device__ inline void mf_record_frags(const float* rec, int lane, uint4& f0, uint4& f1) {
+// the fragment of lane `lane` for one group of 32 records (rec: 32 x float4 in stream order), lengths scaled by s
+inline uint4 mf_record_frag(const float* rec, int lane, float s) {
     const int r = lane & 31, h = lane >> 5;
     int k = 0;
     for (int q = 0; q < 32; q++) if (mf_row_of_record(q) == r) k = q;
     const float* c = rec + 4 * k;
-    unsigned ch[3], cm[3], cl[3], wh, wm, wl;
-    for (int i = 0; i < 3; i++) bf16_split3(c[i], ch[i], cm[i], cl[i]);
-    bf16_split3(c[3], wh, wm, wl);
-    if (h == 0) {
-        f0 = pack8(ch[0], ch[1], ch[2], BF16_ONE, cm[0], cm[1], cm[2], BF16_ONE);
-        f1 = pack8(ch[0], ch[1], ch[2], wh, cm[0], cm[1], cm[2], wm);
+    unsigned ch[3], cl[3], wh, wl;
+    for (int i = 0; i < 3; i++) f16_split2(c[i] * s, false, ch[i], cl[i]);
+    if (fabsf(c[3]) <= 3.0e38f) {
+        f16_split2(c[3] * s * s, true, wh, wl);        // w rounded up: a larger w keeps more
     } else {
-        f0 = pack8(ch[0], ch[1], ch[2], BF16_ONE, cl[0], cl[1], cl[2], 0u);
-        f1 = pack8(ch[0], ch[1], ch[2], wl, cl[0], cl[1], cl[2], BF16_ONE);
+        // a record that is never kept (w = -inf: padding, solids tested for every ray elsewhere) or always kept
+        // (w = +inf: unbounded) carries the centre 0; the largest finite f16 decides N = thr - w against every ordinary
+        // ray's |thr| < MF_RANGE, and unlike an infinity it can meet a zero in the hb product's k slot
+        wh = c[3] < 0.0f ? 0xfbffu : 0x7bffu;
+        wl = 0u;
     }
+    if (h == 0) return pack8(ch[0], ch[1], ch[2], F16_ONE, cl[0], cl[1], cl[2], F16_ONE);
+    return pack8(ch[0], ch[1], ch[2], wh, cl[0], cl[1], cl[2], wl);
 }
 
-struct RayFrag { bf16x8 q0, q1, q2, q3; };
+// ---- device side ------------------------------------------------------------------------------
+union F16Pack { uint4 u; f16x8 v; };
+struct RayFrag { f16x8 q0, q1; };
 
-// the ray operand of the four MFMAs for this lane's half h; a ray that is not of ordinary size gets zeros (its list is
-// marked as overflowed by the caller, so the exact test sees every solid)
-DEV RayFrag mf_ray_frag(const float4 ra, const float4 rb, int h, bool ordinary) {
-    unsigned ah[3], am[3], al[3], oh, om, ol, nh[3], nm[3], nl[3], th, tm, tl;
-    const float a[3] = {ra.x, ra.y, ra.z}, nb[3] = {-rb.x, -rb.y, -rb.z};
-    for (int i = 0; i < 3; i++) { bf16_split3(a[i], ah[i], am[i], al[i]); bf16_split3(nb[i], nh[i], nm[i], nl[i]); }
-    bf16_split3(ra.w, oh, om, ol);
-    bf16_split3(rb.w, th, tm, tl);
-    Bf16Pack p0, p1, p2, p3;
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2;
+DEV unsigned mf_pk(float x, float y) {       // (f16(x), f16(y)) cut towards zero, x in the low half
+    union { fp16x2 h; unsigned u; } p;
+    p.h = __builtin_amdgcn_cvt_pkrtz(x, y);
+    return p.u;
+}
+DEV float mf_lo(unsigned p) { union { unsigned u; fp16x2 h; } q; q.u = p; return (float)q.h[0]; }
+DEV float mf_hi(unsigned p) { union { unsigned u; fp16x2 h; } q; q.u = p; return (float)q.h[1]; }
+
+// scaled ray constants inside the f16 range?  (a ray record of broad_setup that is not of ordinary size carries thr = -inf)
+DEV bool mf_ordinary(const float4 ra, const float4 rb, float s) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(rb.x), __builtin_fabsf(rb.y)), __builtin_fmaxf(__builtin_fabsf(rb.z), __builtin_fabsf(ra.w)));
+    return (rb.w > -__builtin_inff()) & (__builtin_fabsf(rb.w) * s * s < MF_RANGE) & (m * s < MF_RANGE);
+}
+
+// the ray operands of the two MFMAs for this lane's half h; a ray that is not ordinary gets zeros (its list is marked
+// as overflowed by the caller, so the exact test sees every solid)
+DEV RayFrag mf_ray_frag(const float4 ra, const float4 rb, float s, int h, bool ordinary) {
+    const float od = ra.w * s, n0 = -rb.x * s, n1 = -rb.y * s, n2 = -rb.z * s;
+    float thr = rb.w * s * s;
+    if (thr < 0.0f) thr = __builtin_fmaf(thr, 0x1p-20f, thr);      // cut towards zero below: make sure the pieces sum to <= thr
+    // first pieces, their remainders (exact), second pieces
+    const unsigned A01 = mf_pk(ra.x, ra.y), A2o = mf_pk(ra.z, od), N01 = mf_pk(n0, n1), N2t = mf_pk(n2, thr);
+    const unsigned a01 = mf_pk(ra.x - mf_lo(A01), ra.y - mf_hi(A01)), a2o = mf_pk(ra.z - mf_lo(A2o), od - mf_hi(A2o));
+    const unsigned m01 = mf_pk(n0 - mf_lo(N01), n1 - mf_hi(N01)), m2t = mf_pk(n2 - mf_lo(N2t), thr - mf_hi(N2t));
+    F16Pack p0, p1;
     if (h == 0) {
-        p0.u = pack8(ah[0], ah[1], ah[2], oh, ah[0], ah[1], ah[2], om);
-        p1.u = pack8(al[0], al[1], al[2], 0u, am[0], am[1], am[2], 0u);
-        p2.u = pack8(nh[0], nh[1], nh[2], BF16_MINUS_ONE, nh[0], nh[1], nh[2], BF16_MINUS_ONE);
-        p3.u = pack8(nl[0], nl[1], nl[2], tm, nm[0], nm[1], nm[2], tl);
+        p0.u = make_uint4(A01, A2o, A01, (A2o & 0xffffu) | (a2o & 0xffff0000u));
+        p1.u = make_uint4(N01, N2t, N01, (N2t & 0xffffu) | (m2t & 0xffff0000u));
     } else {
-        p0.u = pack8(am[0], am[1], am[2], ol, ah[0], ah[1], ah[2], 0u);
-        p1.u = zero;
-        p2.u = pack8(nm[0], nm[1], nm[2], BF16_MINUS_ONE, nh[0], nh[1], nh[2], th);
-        p3.u = zero;
+        const unsigned al2 = a2o & 0xffffu, nl2 = (m2t & 0xffffu) | (F16_MINUS_ONE << 16);
+        p0.u = make_uint4(a01, al2, a01, al2);
+        p1.u = make_uint4(m01, nl2, m01, nl2);
     }
-    if (!ordinary) { p0.u = zero; p1.u = zero; p2.u = zero; p3.u = zero; }
+    if (!ordinary) { p0.u = make_uint4(0u, 0u, 0u, 0u); p1.u = p0.u; }
     RayFrag f;
-    f.q0 = p0.v; f.q1 = p1.v; f.q2 = p2.v; f.q3 = p3.v;
+    f.q0 = p0.v; f.q1 = p1.v;
     return f;
 }
 
-// keep bits of this lane's ray against the 16 records its lane half sees: bit 15 - reg = record 16 h + reg of the group
-DEV unsigned mf_keep16(const uint4 f0u, const uint4 f1u, const RayFrag& rf) {
-    Bf16Pack f0, f1;
-    f0.u = f0u; f1.u = f1u;
+// the two products of one tile (32 rays) with one group (32 records): hb and N = thr - nq, 16 values each per lane
+DEV void mf_products(const uint4 fu, const RayFrag& rf, f32x16& hb, f32x16& n) {
+    F16Pack f;
+    f.u = fu;
     const f32x16 zero = {0};
-    f32x16 hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.v, rf.q0, zero, 0, 0, 0);
-    hb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.v, rf.q1, hb, 0, 0, 0);
-    f32x16 n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.v, rf.q2, zero, 0, 0, 0);
-    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.v, rf.q3, n, 0, 0, 0);
-    unsigned m = 0;
-#if MF_PK_FMA
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-        const f32x2 x = {hb[i], hb[i + 1]}, y = {n[i], n[i + 1]};
-        const f32x2 t = __builtin_elementwise_fma(-x, x, y);
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[0]), 31u);
-        m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[1]), 31u);
-    }
-#else
-#pragma unroll
-    for (int i = 0; i < 16; i++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(__builtin_fmaf(-hb[i], hb[i], n[i])), 31u);
-#endif
-    return m;
+    hb = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v, rf.q0, zero, 0, 0, 0);
+    n = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v, rf.q1, zero, 0, 0, 0);
 }
 
-// a ray record of broad_setup that is not of ordinary size carries thr = -inf
-DEV bool mf_ordinary(const float4 rb) { return rb.w > -__builtin_inff(); }
+// keep bits of this lane's ray against the 16 records its lane half sees: bit 15 - reg = record 16 h + reg of the group
+DEV unsigned mf_signs(const f32x16& hb, const f32x16& n) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m = __builtin_amdgcn_alignbit(m, __float_as_uint(__builtin_fmaf(-hb[i], hb[i], n[i])), 31u);
+    return m;
+}
 
 #ifndef MF_TILES_N
 #define MF_TILES_N 2
@@ -162,7 +219,7 @@ DEV unsigned mf_from_upper_half(unsigned v) {
 // in LDS.  SLICED: several workgroups scan different groups for the same rays and append through the list's counter;
 // otherwise a ray's list is this lane's alone and its length stays in a register (no memory wait inside the loop).
 template <int BLOCK, bool SLICED>
-DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_cnt, unsigned count, unsigned nbatches,
+DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, unsigned* cand_cnt, unsigned count, unsigned nbatches,
                         unsigned batch0, unsigned batch_step, int g0, int g_begin, int g_end, bool first_window) {
     constexpr unsigned per_block = (BLOCK / 64) * MF_TILES * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
@@ -178,8 +235,8 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
             const bool valid = pos[t] < count;
             const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
             const float4 ra = valid ? w.rec[0][pos[t]] : none, rb = valid ? w.rec[1][pos[t]] : none;
-            const bool ordinary = mf_ordinary(rb);
-            rf[t] = mf_ray_frag(ra, rb, h, ordinary);
+            const bool ordinary = mf_ordinary(ra, rb, scale);
+            rf[t] = mf_ray_frag(ra, rb, scale, h, ordinary);
             own[t] = valid && h == 0;                 // the lower lane half appends for the ray
             n[t] = 0;
             if (own[t]) {
@@ -189,27 +246,71 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
             if (!ordinary) own[t] = false;
             out[t] = w.cand + ((size_t)n[t] * cstride + pos[t]);      // not used by a lane that does not own a ray
         }
-        for (int g = g_begin; g < g_end; g++) {
-            const uint4 f0 = mf_lds[(g * 2 + 0) * 64 + lane], f1 = mf_lds[(g * 2 + 1) * 64 + lane];
-            const unsigned j = (unsigned)(g0 + g);
-#pragma unroll
-            for (int t = 0; t < MF_TILES; t++) {
-                const unsigned mine = mf_keep16(f0, f1, rf[t]);
-                const unsigned other = mf_from_upper_half(mine);
-                const unsigned full = (mine << 16) | other;       // meaningful in the lower lane half
-                if (full != 0u && own[t]) {
-                    if (SLICED) {
-                        const unsigned at = atomicAdd(&cand_cnt[pos[t]], 1u);
-                        if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + pos[t]] = make_uint2(j, full);
-                    } else {
-                        // past the cap the list only counts on; such a count is written out as overflow
-                        if (n[t] < (unsigned)WF_CAND_CAP) *out[t] = make_uint2(j, full);
-                        out[t] += cstride;
-                        n[t]++;                            // at most one per group of the stream on top of CAP + 1: no wrap
+        // one (tile, group) result: the two lane halves' bits joined, then the entry appended to the ray's list
+        auto consume = [&](int t, int g, const f32x16& hb, const f32x16& nn) {
+            const unsigned mine = mf_signs(hb, nn);
+            const unsigned other = mf_from_upper_half(mine);
+            const unsigned full = (mine << 16) | other;       // meaningful in the lower lane half
+            if (full != 0u && own[t]) {
+                const unsigned j = (unsigned)(g0 + g);
+                if (SLICED) {
+                    const unsigned at = atomicAdd(&cand_cnt[pos[t]], 1u);
+                    if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + pos[t]] = make_uint2(j, full);
+                } else {
+                    // past the cap the list only counts on; such a count is written out as overflow
+                    if (n[t] < (unsigned)WF_CAND_CAP) *out[t] = make_uint2(j, full);
+                    out[t] += cstride;
+                    n[t]++;                            // at most one per group of the stream on top of CAP + 1: no wrap
+                }
+            }
+        };
+#if MF_PIPE
+        // Software pipeline over the (group, tile) sequence: the four MFMAs of the next item are issued before the
+        // vector instructions that turn the current item's products into keep bits, so the matrix pipe works on
+        // one accumulator pair while the vector ALU reads the other.
+        static_assert(MF_TILES == 1 || MF_TILES == 2, "the pipeline below is written for one or two tiles");
+        if (g_begin < g_end) {
+            f32x16 hbA, nA, hbB, nB;
+            uint4 f = mf_lds[g_begin * MF_GROUP_WORDS + lane];
+            mf_products(f, rf[0], hbA, nA);
+            if (MF_TILES == 2) {
+                for (int g = g_begin; g < g_end; g++) {
+                    mf_products(f, rf[MF_TILES - 1], hbB, nB);
+                    consume(0, g, hbA, nA);
+                    if (g + 1 < g_end) {
+                        f = mf_lds[(g + 1) * MF_GROUP_WORDS + lane];
+                        mf_products(f, rf[0], hbA, nA);
                     }
+                    consume(MF_TILES - 1, g, hbB, nB);
+                }
+            } else {
+                for (int g = g_begin; g < g_end; g += 2) {
+                    const bool has1 = g + 1 < g_end;
+                    if (has1) {
+                        f = mf_lds[(g + 1) * MF_GROUP_WORDS + lane];
+                        mf_products(f, rf[0], hbB, nB);
+                    }
+                    consume(0, g, hbA, nA);
+                    if (!has1) break;
+                    if (g + 2 < g_end) {
+                        f = mf_lds[(g + 2) * MF_GROUP_WORDS + lane];
+                        mf_products(f, rf[0], hbA, nA);
+                    }
+                    consume(0, g + 1, hbB, nB);
                 }
             }
         }
+#else
+        for (int g = g_begin; g < g_end; g++) {
+            const uint4 f = mf_lds[g * MF_GROUP_WORDS + lane];
+#pragma unroll
+            for (int t = 0; t < MF_TILES; t++) {
+                f32x16 hb, nn;
+                mf_products(f, rf[t], hb, nn);
+                consume(t, g, hb, nn);
+            }
+        }
+#endif
         if (!SLICED) {
 #pragma unroll
             for (int t = 0; t < MF_TILES; t++) if (own[t]) cand_cnt[pos[t]] = n[t] > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n[t];
@@ -219,7 +320,7 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, unsigned* cand_c
 
 // Same contract as broad_kernel: for every queued ray the non-zero 32-record keep masks, appended to its list.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups) {
+__global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
     extern __shared__ uint4 mf_lds[];
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
@@ -238,31 +339,32 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, con
         const int g0 = win * win_groups;
         const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
         if (win > 0) __syncthreads();
-        for (int i = threadIdx.x; i < gn * (MF_GROUP_BYTES / 16); i += BLOCK) mf_lds[i] = frags[(size_t)g0 * (MF_GROUP_BYTES / 16) + i];
+        for (int i = threadIdx.x; i < gn * MF_GROUP_WORDS; i += BLOCK) mf_lds[i] = frags[(size_t)g0 * MF_GROUP_WORDS + i];
         __syncthreads();
         if (slices > 1) {
             const unsigned slice = blockIdx.x / nbatches;
-            mf_scan_window<BLOCK, true>(w, mf_lds, cand_cnt, count, nbatches, blockIdx.x % nbatches, nbatches, g0,
+            mf_scan_window<BLOCK, true>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x % nbatches, nbatches, g0,
                                         (int)((unsigned)gn * slice / slices), (int)((unsigned)gn * (slice + 1) / slices), true);
         } else {
-            mf_scan_window<BLOCK, false>(w, mf_lds, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0);
+            mf_scan_window<BLOCK, false>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0);
         }
     }
 }
 
 // self-test: keep masks of n_rays rays (records of broad_setup in ra/rb) against n_groups groups, masks[ray * n_groups + g]
-__global__ __launch_bounds__(64) void selftest_mfma_kernel(int n_rays, const float4* ra, const float4* rb, const uint4* frags, int n_groups, unsigned* masks) {
+__global__ __launch_bounds__(64) void selftest_mfma_kernel(int n_rays, const float4* ra, const float4* rb, const uint4* frags, int n_groups, float scale, unsigned* masks) {
     const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
     for (int tile = blockIdx.x; tile * 32 < n_rays; tile += gridDim.x) {
         const int ray = tile * 32 + r;
         const bool valid = ray < n_rays;
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
         const float4 a = valid ? ra[ray] : z, b = valid ? rb[ray] : z;
-        const bool ordinary = mf_ordinary(b);
-        const RayFrag rf = mf_ray_frag(a, b, h, ordinary);
+        const bool ordinary = mf_ordinary(a, b, scale);
+        const RayFrag rf = mf_ray_frag(a, b, scale, h, ordinary);
         for (int g = 0; g < n_groups; g++) {
-            const uint4 f0 = frags[(size_t)(g * 2 + 0) * 64 + lane], f1 = frags[(size_t)(g * 2 + 1) * 64 + lane];
-            const unsigned mine = mf_keep16(f0, f1, rf);
+            f32x16 hb, nn;
+            mf_products(frags[(size_t)g * MF_GROUP_WORDS + lane], rf, hb, nn);
+            const unsigned mine = mf_signs(hb, nn);
             const unsigned other = mf_from_upper_half(mine);
             if (valid && h == 0) masks[(size_t)ray * n_groups + g] = ordinary ? ((mine << 16) | other) : 0xffffffffu;
         }

@@ -38,7 +38,7 @@ for row in csv.DictReader(open(os.path.join(src, 'trace', 'vm_kernel_stats.csv')
 wk = os.path.join(src, 'trace_walk', 'vm_kernel_stats.csv')
 if os.path.exists(wk):
     shutil.copy(wk, os.path.join(dst, prefix + '_walk_kernel_stats.csv'))
-    lines += ['', '## the same frames with RT_OPT_ACCEL = 1 (walk_kernel in place of broad_kernel), rocprofv3 --kernel-trace --stats', '',
+    lines += ['', '## the same frames with RT_OPT_ACCEL = 1 (walk_kernel in place of the scan), rocprofv3 --kernel-trace --stats', '',
               '| kernel | calls | avg us | total ms | ms per frame | % |', '|---|---|---|---|---|---|']
     for row in csv.DictReader(open(wk)):
         tot = float(row['TotalDurationNs']) / 1e6
@@ -57,6 +57,8 @@ for (k, c), v in sorted(ft.items()):
 st, sn = pmc('pmc_sq')
 st2, _ = pmc('pmc_sq2')
 st.update(st2)
+st3, _ = pmc('pmc_sq3')
+st.update(st3)
 if st:
     lines += ['', '## SQ counters per frame', '', '| kernel | counter | total |', '|---|---|---|']
     for (k, c), v in sorted(st.items()):
