@@ -96,9 +96,9 @@ def test_broad_phase_is_conservative(renderer):
 
 
 def test_matrix_core_broad_phase_is_conservative(renderer):
-    """The broad phase on the matrix cores (bf16 pieces, four MFMAs per 32 x 32 pairs): no (ray, sphere) pair with a
+    """The broad phase on the matrix cores (f16 pieces, two MFMAs per 32 x 32 pairs): no (ray, sphere) pair with a
     non-negative exact discriminant may be dropped -- every ray against every sphere of a cloud, plus rays aimed at the
-    silhouettes -- and it must still filter."""
+    silhouettes, from inside the cloud and from thousands of units away -- and it must still filter."""
     rng = np.random.default_rng(11)
     n_rec, n_rays = 700, 4096                         # not multiples of 32: padded groups and a ragged last ray tile
     c = rng.uniform(-40, 40, (n_rec, 3))
@@ -126,6 +126,14 @@ def test_matrix_core_broad_phase_is_conservative(renderer):
     own = keep[np.arange(n_rays), pick]
     own_disc = disc[np.arange(n_rays), pick]
     assert own[(own_disc >= 0)].all() and (own_disc >= 0).sum() > 500
+    # the same silhouettes seen from far outside (the test moves the origin along the line; the f16 range must hold)
+    far_o = aim + tgt * 0.0 - d * rng.uniform(2e3, 2e4, n_rays)[:, None]
+    keep_far = renderer.selftest_broad_mfma(far_o, d, c, r)
+    oc = far_o[:, None, :] - c[None, :, :]
+    hb = (d[:, None, :] * oc).sum(2)
+    disc_far = hb * hb - ((oc * oc).sum(2) - (r * r)[None, :])
+    assert not ((disc_far >= 1e-6) & ~keep_far).any()      # (the discriminant itself is computed here with |o| ~ 1e4: ~1e-8 noise)
+    assert not keep_far.all(1).any() and keep_far.mean() < 0.02
     # rays that are not of ordinary size keep everything
     o2 = o[:64].copy(); o2[::2, 0] = 1e30; o2[1::2, 1] = np.nan
     assert renderer.selftest_broad_mfma(o2, d[:64], c, r).all()
