@@ -87,11 +87,11 @@ def measured_traffic(kernel_prefix, key="bytes_per_frame"):
 
 
 EXECUTED_FLOP_PER_TEST = 15     # what broad_kernel executes per (ray, record): 7 fma + 1 sub (+ 1 bit operation, not counted)
-# broad_mfma_kernel (the default): four v_mfma_f32_32x32x16_bf16 (32*32*16*2 FLOP each) per 32 rays x 32 records, and on
+# broad_mfma_kernel (the default): two v_mfma_f32_32x32x16_f16 (32*32*16*2 FLOP each) per 32 rays x 32 records, and on
 # the vector ALU one fma per pair (+ 1 bit operation, not counted)
-MFMA_FLOP_PER_TEST = 4 * 32 * 32 * 16 * 2 // 1024
+MFMA_FLOP_PER_TEST = 2 * 32 * 32 * 16 * 2 // 1024
 MFMA_VALU_FLOP_PER_TEST = 2
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense f16 / bf16
 
 
 def main():
@@ -264,8 +264,8 @@ def main():
         pairs = tm["rays"] * padded
         if on_mfma:
             executed = MFMA_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
-            executed_peak = BF16_MFMA_PEAK_TFLOPS
-            executed_basis = ("%d bf16 MFMA FLOP x rays x padded records (%d) / %s time, against the dense bf16 MFMA peak; beside it "
+            executed_peak = F16_MFMA_PEAK_TFLOPS
+            executed_basis = ("%d f16 MFMA FLOP x rays x padded records (%d) / %s time, against the dense f16 MFMA peak; beside it "
                               "%d FP32 FLOP per pair on the vector ALU" % (MFMA_FLOP_PER_TEST, padded, kname, MFMA_VALU_FLOP_PER_TEST))
         else:
             executed = EXECUTED_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
@@ -277,7 +277,7 @@ def main():
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": ("bf16x3 MFMA + f32 broad phase" if on_mfma else "f32 broad phase") + " + f64 exact phase", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f16x2 MFMA + f32 broad phase" if on_mfma else "f32 broad phase") + " + f64 exact phase", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
                        "rays_per_frame": rays_frame, "tile_rows": args.tile_rows,
