@@ -286,6 +286,13 @@ int rt_gather_source_row(int height, int tile_rows, int world, int pad_rows, int
  * Returns 1 and (centre[3], radius) when the region is bounded, 0 when the face is tested for every ray, < 0 on error. */
 int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius);
 
+/* Host-only self-test (no GPU call): how broad_mfma_kernel's record table represents one broad-phase record
+ * (cx, cy, cz, w = R^2 - |c|^2) of a scene whose largest record extent is cmax.  scale: the power of two by which lengths
+ * are multiplied; pieces[8]: the two f16 pieces (as doubles) of s cx, s cy, s cz and s^2 w.  The pieces of a coordinate
+ * sum to it within 2^-21 of its magnitude, those of w to at least s^2 w (w is rounded towards "keep"); an infinite w
+ * (never / always kept record) becomes -/+ 65504. */
+int rt_mfma_record_pieces(const double* record, double cmax, double* scale, double* pieces);
+
 /* Self-test of the broad phase on the matrix cores: every one of n_rays rays against every one of n_rec bounding spheres,
  * evaluated exactly as broad_mfma_kernel does.  masks: uint32[n_rays * ceil(n_rec / 32)] (HOST); bit 31 - k of
  * masks[ray * groups + g] is set iff record 32 g + k is kept for the ray. */

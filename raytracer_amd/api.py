@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound",
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
            "rt_multi_render_image", "rt_multi_last_ms", "rt_multi_last_error", "rt_gather_source_row")
 
@@ -119,6 +119,8 @@ def load_library(path: str = LIB_PATH):
     l.rt_multi_last_error.argtypes = [C.c_void_p]
     l.rt_gather_source_row.restype = C.c_int
     l.rt_gather_source_row.argtypes = [C.c_int] * 5
+    l.rt_mfma_record_pieces.restype = C.c_int
+    l.rt_mfma_record_pieces.argtypes = [dp, C.c_double, C.POINTER(C.c_double), dp]
     l.rt_face_bound.restype = C.c_int
     l.rt_face_bound.argtypes = [C.c_int, dp, dp, dp, dp]
     _lib = l
@@ -136,6 +138,17 @@ def face_bound(verts, normal):
     if rc < 0:
         raise RtError(rc, "rt_face_bound: bad argument")
     return (c, float(r.value)) if rc == 1 else None
+
+
+def mfma_record_pieces(record, cmax):
+    """(scale, pieces[4][2]) of one broad-phase record (cx, cy, cz, w) in the matrix-core scan's f16 table.  Host only."""
+    rec = np.ascontiguousarray(record, dtype=np.float64).reshape(4)
+    sc = C.c_double(0.0)
+    out = np.zeros(8)
+    rc = load_library().rt_mfma_record_pieces(_dp(rec), float(cmax), C.byref(sc), _dp(out))
+    if rc < 0:
+        raise RtError(rc, "rt_mfma_record_pieces: bad argument")
+    return float(sc.value), out.reshape(4, 2)
 
 
 def rows_for_rank(height, tile_rows, rank, world):

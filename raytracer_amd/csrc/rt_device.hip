@@ -179,6 +179,21 @@ int rt_face_bound(int n_verts, const double* verts, const double* normal, double
     return face_bound(verts, n_verts, normal, centre, radius) ? 1 : 0;
 }
 
+int rt_mfma_record_pieces(const double* record, double cmax, double* scale, double* pieces) {
+    if (!record || !scale || !pieces) return RT_ERR_ARG;
+    const float s = mf_scale_for((float)cmax);
+    *scale = (double)s;
+    for (int i = 0; i < 4; i++) {
+        unsigned h, l;
+        const float x = (float)record[i] * (i < 3 ? s : s * s);
+        if (i == 3 && !(fabsf((float)record[3]) <= 3.0e38f)) { h = record[3] < 0 ? 0xfbffu : 0x7bffu; l = 0u; }   // as mf_record_frag
+        else f16_split2(x, i == 3, h, l);
+        pieces[2 * i] = (double)f16_value(h);
+        pieces[2 * i + 1] = (double)f16_value(l);
+    }
+    return RT_OK;
+}
+
 int rt_rows_for_rank(int height, int tile_rows, int rank, int world) {
     if (height < 0 || tile_rows < 1 || world < 1 || rank < 0 || rank >= world) return RT_ERR_ARG;
     int rows = 0;

@@ -252,6 +252,46 @@ def test_numpy_expose_mirror_converts_like_x86_at_the_edges():
         assert np.array_equal(api.expose(rgb, exposure, 0), want), exposure
 
 
+def _is_f16(v):
+    """v (a double) is a value of IEEE binary16, subnormals included"""
+    if v == 0.0 or not np.isfinite(v):
+        return True
+    m, e = np.frexp(abs(v))                      # |v| = m 2^e, m in [0.5, 1)
+    if e > 16:
+        return False
+    step = 2.0 ** (max(e, -13) - 11)              # 11 significant bits; a fixed step of 2^-24 below 2^-14
+    return (abs(v) / step) == np.floor(abs(v) / step)
+
+
+def test_matrix_core_record_pieces_are_f16_and_round_towards_keep():
+    """The f16 table of the scan on the matrix cores: every piece is a binary16 value, a coordinate's two pieces give it
+    back to 2^-21 of its magnitude, w's pieces never sum to less than w (a larger w keeps more), the scale is the power of
+    two that puts the scene's extent in (32, 64], and never / always kept records carry -/+ 65504."""
+    rng = np.random.default_rng(4)
+    for cmax in (0.7, 33.3, 47.0, 64.0, 65.0, 900.0, 3.0e5, 1.0e-3):
+        scale, _ = api.mfma_record_pieces([0, 0, 0, 0], cmax)
+        m, e = np.frexp(scale)
+        assert m == 0.5 and 32.0 < cmax * scale * (1 + 1e-12) <= 64.0 * (1 + 1e-6)
+        for _ in range(200):
+            c = rng.uniform(-1, 1, 3) * cmax * rng.choice([1.0, 1e-2, 1e-5])
+            R = rng.uniform(0, 0.3) * cmax
+            w = float(np.float32(R * R - c @ c))
+            c = np.float32(c).astype(np.float64)
+            s, p = api.mfma_record_pieces([*c, w], cmax)
+            assert all(_is_f16(v) for v in p.ravel())
+            for i in range(3):
+                x = c[i] * s
+                assert abs(p[i, 0] + p[i, 1] - x) <= abs(x) * 2.0 ** -21 + 2.0 ** -24
+                assert abs(p[i, 0]) <= abs(x) and p[i, 0] * x >= 0       # cut towards zero
+            ws = float(np.float32(w * s * s))
+            assert p[3, 0] + p[3, 1] >= ws
+            assert p[3, 0] + p[3, 1] - ws <= abs(ws) * 2.0 ** -20 + 2.0 ** -23
+    _, p = api.mfma_record_pieces([0, 0, 0, -np.inf], 10.0)
+    assert tuple(p[3]) == (-65504.0, 0.0)
+    _, p = api.mfma_record_pieces([0, 0, 0, np.inf], 10.0)
+    assert tuple(p[3]) == (65504.0, 0.0)
+
+
 def test_gather_source_row_matches_the_partition():
     """rt_gather_source_row (host arithmetic of the in-library gather) against the packing order of the partition: rank r's
     buffer holds its rows in ascending order, buffers are stacked by rank with pad_rows rows each."""
