@@ -30,29 +30,17 @@
 // row that lane half h' reads in register reg, so a lane's 16 sign bits are the keep bits of 16 consecutive records.
 #pragma once
 
-#ifndef MF_USE_SHFL
-#define MF_USE_SHFL 0
-#endif
-#ifndef MF_PIPE
-#define MF_PIPE 0
-#endif
-#ifndef MF_BLOCK_N
-#define MF_BLOCK_N 512
-#endif
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int MF_BLOCK = MF_BLOCK_N;           // threads per workgroup of broad_mfma_kernel
+constexpr int MF_BLOCK = 512;                 // threads per workgroup of broad_mfma_kernel (256 to 1024, 1 or 2 tiles per wave: the same time)
 constexpr int MF_GROUP_BYTES = 1024;          // one fragment x 64 lanes x 16 bytes per group of 32 records
 constexpr int MF_GROUP_WORDS = MF_GROUP_BYTES / 16;
 constexpr int MF_WINDOW_GROUPS = 64;          // most groups per LDS window (64 KiB: two workgroups per CU)
-#ifndef MF_RANGE_V
-#define MF_RANGE_V 60000.0f
-#endif
-constexpr float MF_RANGE = MF_RANGE_V;          // scaled ray constants must stay below this (f16 ends at 65504)
+constexpr float MF_RANGE = 60000.0f;          // scaled ray constants must stay below this (f16 ends at 65504)
 
 // ---- host side: the pieces of the records -------------------------------------------------------
 // x cut to the f16 grid towards zero (11 significant bits; multiples of 2^-24 below 2^-14): exact float arithmetic
@@ -199,21 +187,12 @@ DEV unsigned mf_signs(const f32x16& hb, const f32x16& n) {
     return m;
 }
 
-#ifndef MF_TILES_N
-#define MF_TILES_N 2
-#endif
-constexpr int MF_TILES = MF_TILES_N;          // ray tiles (of 32 rays) per wave and batch
+constexpr int MF_TILES = 2;                   // ray tiles (of 32 rays) per wave and batch
 
 // For a lane of the lower half: the value of its partner lane (lane + 32).  v_permlane32_swap exchanges the upper half
 // of its first operand with the lower half of its second, so with both operands = v the second comes back holding the
 // upper half's values in the lower lanes.  (Lanes of the upper half get their own value back.)
-DEV unsigned mf_from_upper_half(unsigned v) {
-#if MF_USE_SHFL
-    return (unsigned)__shfl_xor((int)v, 32, 64);
-#else
-    return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1];
-#endif
-}
+DEV unsigned mf_from_upper_half(unsigned v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }
 
 // One workgroup's share of a window: batches of BLOCK/64 x MF_TILES x 32 rays against the groups [g_begin, g_end) staged
 // in LDS.  SLICED: several workgroups scan different groups for the same rays and append through the list's counter;
@@ -264,43 +243,6 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
                 }
             }
         };
-#if MF_PIPE
-        // Software pipeline over the (group, tile) sequence: the four MFMAs of the next item are issued before the
-        // vector instructions that turn the current item's products into keep bits, so the matrix pipe works on
-        // one accumulator pair while the vector ALU reads the other.
-        static_assert(MF_TILES == 1 || MF_TILES == 2, "the pipeline below is written for one or two tiles");
-        if (g_begin < g_end) {
-            f32x16 hbA, nA, hbB, nB;
-            uint4 f = mf_lds[g_begin * MF_GROUP_WORDS + lane];
-            mf_products(f, rf[0], hbA, nA);
-            if (MF_TILES == 2) {
-                for (int g = g_begin; g < g_end; g++) {
-                    mf_products(f, rf[MF_TILES - 1], hbB, nB);
-                    consume(0, g, hbA, nA);
-                    if (g + 1 < g_end) {
-                        f = mf_lds[(g + 1) * MF_GROUP_WORDS + lane];
-                        mf_products(f, rf[0], hbA, nA);
-                    }
-                    consume(MF_TILES - 1, g, hbB, nB);
-                }
-            } else {
-                for (int g = g_begin; g < g_end; g += 2) {
-                    const bool has1 = g + 1 < g_end;
-                    if (has1) {
-                        f = mf_lds[(g + 1) * MF_GROUP_WORDS + lane];
-                        mf_products(f, rf[0], hbB, nB);
-                    }
-                    consume(0, g, hbA, nA);
-                    if (!has1) break;
-                    if (g + 2 < g_end) {
-                        f = mf_lds[(g + 2) * MF_GROUP_WORDS + lane];
-                        mf_products(f, rf[0], hbA, nA);
-                    }
-                    consume(0, g + 1, hbB, nB);
-                }
-            }
-        }
-#else
         for (int g = g_begin; g < g_end; g++) {
             const uint4 f = mf_lds[g * MF_GROUP_WORDS + lane];
 #pragma unroll
@@ -310,7 +252,6 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
                 consume(t, g, hb, nn);
             }
         }
-#endif
         if (!SLICED) {
 #pragma unroll
             for (int t = 0; t < MF_TILES; t++) if (own[t]) cand_cnt[pos[t]] = n[t] > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n[t];
