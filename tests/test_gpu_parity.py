@@ -207,6 +207,23 @@ def test_moved_camera_matches_oracle(renderer, golden_dir):
     assert not np.array_equal(renderer.render()["rgb"], g["rgb"])       # the key has an effect
 
 
+@pytest.mark.parametrize("k", [4096.0, 0.25])
+def test_scaled_scene_matches_oracle(renderer, golden_dir, k):
+    """The same room k times as large (and as far from the origin: the matrix-core scan's f16 table works on lengths
+    scaled by a power of two chosen from the scene, 2^-11 and 2^3 here).  Pinned by the oracle only."""
+    sc = S.read_json_scene(os.path.join(golden_dir, "small_mixed.scene.json"))
+    sc.prims[:, S.PR_A:S.PR_A + 3] *= k
+    sc.prims[:, S.PR_RADIUS] *= k
+    sc.verts *= k
+    h = sc.header
+    h["scale"] = h["scale"] / k
+    h["lens_radius"] = h["lens_radius"] * k
+    h["focal_length"] = h["focal_length"] * k
+    h["camera"] = [c * k for c in S.DEFAULT_CAMERA]
+    g, _ = _compare(renderer, sc, f"small_mixed x{k}")
+    assert g["rays"] > 10_000
+
+
 def test_camera_beyond_the_box_test_range(renderer, golden_dir):
     """Origins of 1e200: beyond the range for which the always-tested walls' coordinate-range test is proven, so every
     such ray takes the general test (whole-wave scan in the pipeline, the loop in the single-kernel renderer).  Pinned
