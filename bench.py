@@ -97,8 +97,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense f16 / bf16
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)     # 1.2 s of frames on C3: long enough for an outside sampler to see the GPU busy
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(synth.CONFIGS))
     ap.add_argument("--width", type=int, default=None, help="override the frame width (height follows 16:9)")
     ap.add_argument("--tile-rows", type=int, default=None,
