@@ -599,7 +599,9 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
         for (int p = 0; p < nsub; p++) wp[p].kp.wide = 1;
     }
-    unsigned sgrid = (unsigned)h->cu_count * 16u;
+    // shade_kernel: 8 workgroups per CU, two generations of the 4 that are resident (C3 frame: 4 -> 6.17, 8 -> 6.06,
+    // 16 -> 6.15, 32 -> 6.27 ms)
+    unsigned sgrid = (unsigned)h->cu_count * 8u;
     if (const char* e = getenv("RT_SHADE_GRID")) sgrid = (unsigned)h->cu_count * (unsigned)atoi(e);
     h->last_streams = 0;
     h->broad_ev_used = 0;
