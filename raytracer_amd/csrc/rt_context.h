@@ -27,6 +27,11 @@ struct rt_context {
     void* d_mats = nullptr;
     uint4* d_frags = nullptr; int n_groups = 0;   // broad_mfma_kernel: record fragments, 1 KiB per group of 32 records
     float mf_scale = 1.0f;                        //   and the power of two by which its lengths are scaled
+    int mf_win_groups = 0, mf_windows = 0;        //   groups per LDS window, windows
+    bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
+    bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
+    unsigned* d_mf_perm = nullptr;                //   place in the table's order -> file index of the solid
+    double* d_mf_cand = nullptr;                  //   place -> (point a, radius) of the solid, for the exact phase
     void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;
     // uniform grid over the bounded solids (walk_kernel); grid_ok: built and usable for this scene
     uint4* d_cells = nullptr; float4* d_item_rec = nullptr; uint2* d_item_aux = nullptr;
@@ -122,8 +127,8 @@ struct DevMem {
 
 void free_scene(rt_context* h) {
     hipFree(h->d_records); hipFree(h->d_chunks); hipFree(h->d_prims); hipFree(h->d_verts); hipFree(h->d_mats); hipFree(h->d_always);
-    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux); hipFree(h->d_frags);
-    h->d_frags = nullptr; h->n_groups = 0;
+    hipFree(h->d_cells); hipFree(h->d_item_rec); hipFree(h->d_item_aux); hipFree(h->d_frags); hipFree(h->d_mf_perm); hipFree(h->d_mf_cand);
+    h->d_frags = nullptr; h->d_mf_perm = nullptr; h->d_mf_cand = nullptr; h->n_groups = 0;
     h->d_cells = nullptr; h->d_item_rec = nullptr; h->d_item_aux = nullptr; h->grid_ok = false;
     h->d_records = h->d_chunks = h->d_prims = h->d_verts = h->d_mats = h->d_always = nullptr;
     h->have_scene = false;
@@ -420,6 +425,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.max_verts = RT_MAXV;
     kp.cmax = h->cmax;
     kp.wide = 0;
+    kp.mf_perm = nullptr; kp.mf_cand = nullptr;
     for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
     kp.records = (const float4*)h->d_records;
     kp.chunks = (const ChunkDesc*)h->d_chunks;
@@ -465,9 +471,116 @@ std::vector<uint4> mf_build_frags(const std::vector<float>& rec, float s) {
     return fr;
 }
 
-template <int BLOCK>
+// The scene's table for broad_mfma_kernel.  The records are put in an order of their own -- bounded ones along a Morton
+// curve through their centres, so that 32 consecutive records are neighbours in space, then the unbounded ones; records
+// that are never kept (solids of the always-tested table) are left out -- and `perm` leads from a place in that order
+// back to the solid's file index (list entries name places; the exact phase looks the file index up).  Every group of 32
+// gets a bounding sphere of its members' bounding spheres; these "group records", 32 to a fragment like ordinary
+// records, let the kernel ask first which groups any ray of a tile can touch.  Layout: per LDS window its groups'
+// fragments, then the fragments of its group records.
+struct MfTable {
+    std::vector<uint4> frags;
+    std::vector<unsigned> perm;
+    int n_groups = 0, n_windows = 0, win_groups = 0;
+    float scale = 1.0f;
+    double cmax = 0.0;           // largest extent |c| + R over records and group records
+    bool reordered = false;      // false: file order, perm is the identity (places are file indices)
+};
+inline unsigned mf_spread10(unsigned v) {          // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, bool reorder) {
+    MfTable t;
+    t.reordered = reorder;
+    std::vector<int> bounded, unbounded;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n_prims; i++) {
+        const float* r = rec_file + 4 * (size_t)i;
+        if (r[3] == -INFINITY) continue;                       // never kept
+        if (!(fabsf(r[3]) <= 3.0e38f)) { unbounded.push_back(i); continue; }
+        bounded.push_back(i);
+        for (int k = 0; k < 3; k++) { if (r[k] < lo[k]) lo[k] = r[k]; if (r[k] > hi[k]) hi[k] = r[k]; }
+    }
+    std::vector<std::pair<unsigned, int>> keyed;
+    for (int i : bounded) {
+        unsigned q[3];
+        for (int k = 0; k < 3; k++) {
+            const float ext = hi[k] - lo[k];
+            const float u = ext > 0.0f ? (rec_file[4 * (size_t)i + k] - lo[k]) / ext : 0.0f;
+            q[k] = (unsigned)(u * 1023.0f + 0.5f);
+        }
+        keyed.push_back({mf_spread10(q[0]) | (mf_spread10(q[1]) << 1) | (mf_spread10(q[2]) << 2), i});
+    }
+    std::sort(keyed.begin(), keyed.end());
+    const unsigned NONE = 0x7fffffffu;                        // a place that holds no solid
+    if (reorder) {
+        for (auto& kv : keyed) t.perm.push_back((unsigned)kv.second);
+        for (int i : unbounded) t.perm.push_back((unsigned)i);
+    } else {
+        for (int i = 0; i < n_prims; i++) t.perm.push_back((unsigned)i);      // never-kept records stay in their places
+    }
+    while (t.perm.empty() || t.perm.size() % BROAD_GROUP) t.perm.push_back(NONE);
+    t.n_groups = (int)(t.perm.size() / BROAD_GROUP);
+    t.n_windows = (t.n_groups + MF_WINDOW_GROUPS - 1) / MF_WINDOW_GROUPS;
+    t.win_groups = (t.n_groups + t.n_windows - 1) / t.n_windows;
+    // records in table order, and the group records
+    std::vector<float> rec(t.perm.size() * 4), grp((size_t)t.n_groups * 4);
+    t.cmax = cmax_records;
+    for (int g = 0; g < t.n_groups; g++) {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        bool any = false, unb = false;
+        for (int k = 0; k < BROAD_GROUP; k++) {
+            const unsigned i = t.perm[(size_t)g * BROAD_GROUP + k];
+            float* r = &rec[((size_t)g * BROAD_GROUP + k) * 4];
+            if (i == NONE) { r[0] = r[1] = r[2] = 0.0f; r[3] = -INFINITY; continue; }
+            memcpy(r, rec_file + 4 * (size_t)i, 16);
+            any = true;
+            if (!(fabsf(r[3]) <= 3.0e38f)) { unb = true; continue; }
+            const double R = sqrt(fmax(0.0, (double)r[3] + (double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2]));
+            for (int a = 0; a < 3; a++) { if (r[a] - R < blo[a]) blo[a] = r[a] - R; if (r[a] + R > bhi[a]) bhi[a] = r[a] + R; }
+        }
+        float* gr = &grp[(size_t)g * 4];
+        if (!any) { gr[0] = gr[1] = gr[2] = 0.0f; gr[3] = -INFINITY; continue; }
+        if (unb) { gr[0] = gr[1] = gr[2] = 0.0f; gr[3] = INFINITY; continue; }
+        double c[3], R = 0.0;
+        for (int a = 0; a < 3; a++) c[a] = 0.5 * (blo[a] + bhi[a]);
+        for (int k = 0; k < BROAD_GROUP; k++) {
+            const float* r = &rec[((size_t)g * BROAD_GROUP + k) * 4];
+            if (r[3] == -INFINITY) continue;
+            const double Rm = sqrt(fmax(0.0, (double)r[3] + (double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2]));
+            const double d = sqrt((r[0] - c[0]) * (r[0] - c[0]) + (r[1] - c[1]) * (r[1] - c[1]) + (r[2] - c[2]) * (r[2] - c[2])) + Rm;
+            if (d > R) R = d;
+        }
+        const double ext = make_record(c, R * (1.0 + 1e-6) + 1e-30, gr);
+        if (ext > t.cmax) t.cmax = ext;
+    }
+    t.scale = mf_scale_for((float)(t.cmax * (1.0 + 1e-6)));
+    for (int w = 0; w < t.n_windows; w++) {
+        const int g0 = w * t.win_groups, gn = std::min(t.win_groups, t.n_groups - g0);
+        for (int g = g0; g < g0 + gn; g++)
+            for (int lane = 0; lane < 64; lane++) t.frags.push_back(mf_record_frag(&rec[(size_t)g * 4 * BROAD_GROUP], lane, t.scale));
+        for (int l = 0; l * BROAD_GROUP < gn; l++) {
+            float g32[4 * BROAD_GROUP];
+            for (int k = 0; k < BROAD_GROUP; k++) {
+                const int g = l * BROAD_GROUP + k;
+                if (g < gn) memcpy(&g32[4 * k], &grp[(size_t)(g0 + g) * 4], 16);
+                else { g32[4 * k] = g32[4 * k + 1] = g32[4 * k + 2] = 0.0f; g32[4 * k + 3] = -INFINITY; }
+            }
+            for (int lane = 0; lane < 64; lane++) t.frags.push_back(mf_record_frag(g32, lane, t.scale));
+        }
+        // every window but the last is full: the kernel finds window w at w * (win_groups + its group fragments) * 64 words
+    }
+    return t;
+}
+
+template <int BLOCK, bool CULL>
 hipError_t mfma_grid(rt_context* h, size_t lds, unsigned* grid) {
-    auto kern = broad_mfma_kernel<BLOCK>;
+    auto kern = broad_mfma_kernel<BLOCK, CULL>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = h->grid_mult;

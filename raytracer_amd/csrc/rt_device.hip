@@ -120,6 +120,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_OVERLAP")) rt_set_option(h, RT_OPT_OVERLAP, atoi(e));
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
+    if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_BROAD_MFMA")) h->broad_mfma = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
@@ -415,6 +416,16 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     const int always_doubles = (int)alw.size();
     if (alw.empty()) alw.push_back(0.0);
 
+    // the matrix-core scan's table; its group records can reach further out than any record, and cmax covers both
+    // Its own (Morton) record order and the group-record pass pay only where a whole round is camera rays -- one path per
+    // pixel -- and there are groups enough to drop; otherwise the table keeps the file order (consecutive solids of a
+    // scene file tend to be neighbours along some line, which packs a ray's hits into few mask words).
+    int n_bounded = 0;
+    for (int i = 0; i < n_prims; i++) if (!always[i] && br[i] >= 0) n_bounded++;
+    const bool mf_reorder = h->mf_cull && spp == 1 && n_bounded >= 8 * BROAD_GROUP;
+    const MfTable mt = mf_build_table(rec.data(), n_prims, cmax, mf_reorder);
+    if (mt.reordered && mt.cmax > cmax) cmax = mt.cmax;
+
     GridHost gh;
     const bool grid_ok = build_grid(n_prims, pd, bc, br, always, T, h->grid_density, gh);
 
@@ -436,14 +447,24 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     HIP_TRY(h, hipMalloc(&h->d_always, alw.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->d_always, alw.data(), alw.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_always = n_always; h->always_doubles = always_doubles; h->n_box = n_box;
-    {
-        const float mf_scale = mf_scale_for((float)(cmax * (1.0 + 1e-6)));
-        const std::vector<uint4> fr = mf_build_frags(rec, mf_scale);
-        HIP_TRY(h, hipMalloc((void**)&h->d_frags, fr.size() * sizeof(uint4)));
-        HIP_TRY(h, hipMemcpy(h->d_frags, fr.data(), fr.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        h->n_groups = (int)(fr.size() / MF_GROUP_WORDS);
-        h->mf_scale = mf_scale;
+    HIP_TRY(h, hipMalloc((void**)&h->d_frags, mt.frags.size() * sizeof(uint4)));
+    HIP_TRY(h, hipMemcpy(h->d_frags, mt.frags.data(), mt.frags.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (mt.reordered) {
+        HIP_TRY(h, hipMalloc((void**)&h->d_mf_perm, mt.perm.size() * sizeof(unsigned)));
+        HIP_TRY(h, hipMemcpy(h->d_mf_perm, mt.perm.data(), mt.perm.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        // the exact phase's copy of the solids' first 32 bytes in the table's order
+        std::vector<double> mc(mt.perm.size() * 4);
+        for (size_t k = 0; k < mt.perm.size(); k++) {
+            const unsigned i = mt.perm[k];
+            double* c = &mc[4 * k];
+            if (i < (unsigned)n_prims) { c[0] = pd[i].a[0]; c[1] = pd[i].a[1]; c[2] = pd[i].a[2]; c[3] = pd[i].radius; }
+            else { c[0] = c[1] = c[2] = 0.0; c[3] = NAN; }
+        }
+        HIP_TRY(h, hipMalloc((void**)&h->d_mf_cand, mc.size() * sizeof(double)));
+        HIP_TRY(h, hipMemcpy(h->d_mf_cand, mc.data(), mc.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    h->mf_reordered = mt.reordered;
+    h->n_groups = mt.n_groups; h->mf_win_groups = mt.win_groups; h->mf_windows = mt.n_windows; h->mf_scale = mt.scale;
     HIP_TRY(h, hipMalloc(&h->d_records, rec.size() * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(h, hipMalloc(&h->d_prims, pd.size() * sizeof(PrimD)));
@@ -589,15 +610,15 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     const bool use_grid = h->accel && h->grid_ok;
     // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
     const bool use_mfma = h->broad_mfma && !use_grid && h->d_frags;
-    // windows of equal size, at most MF_WINDOW_GROUPS groups each
-    const int mf_windows = (h->n_groups + MF_WINDOW_GROUPS - 1) / MF_WINDOW_GROUPS;
-    const int mf_win_groups = mf_windows ? (h->n_groups + mf_windows - 1) / mf_windows : 1;
-    const size_t mfma_lds = (size_t)mf_win_groups * MF_GROUP_BYTES;
-    unsigned mgrid = 1;
+    // one LDS window: its groups' fragments and those of its group records
+    const int mf_win_groups = h->mf_win_groups;
+    const size_t mfma_lds = (size_t)(mf_win_groups + (mf_win_groups + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_BYTES;
+    unsigned mgrid = 1, mgrid_cull = 1;
     if (use_mfma) {
-        e = mfma_grid<MF_BLOCK>(h, mfma_lds, &mgrid);
+        e = mfma_grid<MF_BLOCK, false>(h, mfma_lds, &mgrid);
+        if (e == hipSuccess && h->mf_reordered) e = mfma_grid<MF_BLOCK, true>(h, mfma_lds, &mgrid_cull);
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
-        for (int p = 0; p < nsub; p++) wp[p].kp.wide = 1;
+        for (int p = 0; p < nsub; p++) { wp[p].kp.wide = 1; wp[p].kp.mf_perm = h->d_mf_perm; wp[p].kp.mf_cand = h->d_mf_cand; }
     }
     // shade_kernel: 8 workgroups per CU, two generations of the 4 that are resident (C3 frame: 4 -> 6.17, 8 -> 6.06,
     // 16 -> 6.15, 32 -> 6.27 ms)
@@ -652,14 +673,27 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                 w.iter = it;
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
                 if (use_grid) { hipLaunchKernelGGL(walk_kernel, dim3((unsigned)h->cu_count * 16u), dim3(256), 0, ss[p], w, h->grid); e = hipGetLastError(); }
-                else if (use_mfma) { hipLaunchKernelGGL(broad_mfma_kernel<MF_BLOCK>, dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale); e = hipGetLastError(); }
+                else if (use_mfma) {
+                    // the camera rays' round of a table in its own order asks the group records first
+                    if (it == 0 && h->mf_reordered)
+                        hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
+                    else
+                        hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
+                    e = hipGetLastError();
+                }
                 else if (h->broad_block == 1024) e = launch_broad<1024>(h, w, bgrid, ss[p]);
                 else if (h->broad_block == 256) e = launch_broad<256>(h, w, bgrid, ss[p]);
                 else e = launch_broad<512>(h, w, bgrid, ss[p]);
                 if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel launch: ") + hipGetErrorString(e));
                 if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
-                if (it == 0) hipLaunchKernelGGL(shade_kernel<true>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), shade_lds, ss[p], w);
-                else hipLaunchKernelGGL(shade_kernel<false>, dim3(sgrid * 256 / SHADE_BLOCK), dim3(SHADE_BLOCK), shade_lds, ss[p], w);
+                const dim3 sg(sgrid * 256 / SHADE_BLOCK), sb(SHADE_BLOCK);
+                if (w.kp.mf_perm) {
+                    if (it == 0) hipLaunchKernelGGL((shade_kernel<true, true>), sg, sb, shade_lds, ss[p], w);
+                    else hipLaunchKernelGGL((shade_kernel<false, true>), sg, sb, shade_lds, ss[p], w);
+                } else {
+                    if (it == 0) hipLaunchKernelGGL((shade_kernel<true, false>), sg, sb, shade_lds, ss[p], w);
+                    else hipLaunchKernelGGL((shade_kernel<false, false>), sg, sb, shade_lds, ss[p], w);
+                }
             }
         }
         e = hipGetLastError();
@@ -708,7 +742,7 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->events_pending = false;
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    unsigned ctrl[8];
+    unsigned ctrl[16];
     HIP_TRY(h, hipMemcpy(ctrl, h->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     uint64_t r = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
     h->timing.kernel_ms = ms;
@@ -720,6 +754,8 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
     h->timing.overflow_rays = ctrl[6];
+    h->timing.broad_tiles = (uint64_t)ctrl[14] | ((uint64_t)ctrl[15] << 32);
+    h->timing.broad_records = (uint64_t)h->n_groups * BROAD_GROUP;
 #if WALK_DEBUG
     {
         unsigned dbg[8];

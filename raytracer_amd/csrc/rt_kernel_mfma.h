@@ -197,9 +197,23 @@ DEV unsigned mf_from_upper_half(unsigned v) { return __builtin_amdgcn_permlane32
 // One workgroup's share of a window: batches of BLOCK/64 x MF_TILES x 32 rays against the groups [g_begin, g_end) staged
 // in LDS.  SLICED: several workgroups scan different groups for the same rays and append through the list's counter;
 // otherwise a ray's list is this lane's alone and its length stays in a register (no memory wait inside the loop).
-template <int BLOCK, bool SLICED>
+// OR over the 64 lanes of a wave (DPP within rows of 16, then the four rows)
+DEV unsigned mf_wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);   // row_mirror
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// CULL: the groups' own bounding spheres ("group records", gn_window of them in fragments that follow the window's
+// groups in LDS) are tested first, and a group is scanned for a tile only if some ray of the tile keeps its group
+// record.  Worth its two extra passes per tile only while the rays of a tile run side by side: the camera rays' round.
+template <int BLOCK, bool SLICED, bool CULL>
 DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, unsigned* cand_cnt, unsigned count, unsigned nbatches,
-                        unsigned batch0, unsigned batch_step, int g0, int g_begin, int g_end, bool first_window) {
+                        unsigned batch0, unsigned batch_step, int g0, int g_begin, int g_end, bool first_window, int gn_window,
+                        unsigned& tiles_done) {
     constexpr unsigned per_block = (BLOCK / 64) * MF_TILES * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const size_t cstride = w.slots;
@@ -243,13 +257,40 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
                 }
             }
         };
+        // which groups of the window each tile has to scan: bit 31 - (g & 31) of word g >> 5 (at most 64 groups a window)
+        unsigned need[MF_TILES][2];
+#pragma unroll
+        for (int t = 0; t < MF_TILES; t++) { need[t][0] = 0xffffffffu; need[t][1] = 0xffffffffu; }
+        if (CULL) {
+            for (int l = 0; l * BROAD_GROUP < gn_window; l++) {
+                const uint4 f = mf_lds[(gn_window + l) * MF_GROUP_WORDS + lane];
+#pragma unroll
+                for (int t = 0; t < MF_TILES; t++) {
+                    f32x16 hb, nn;
+                    mf_products(f, rf[t], hb, nn);
+                    const unsigned mine = mf_signs(hb, nn);
+                    const unsigned full = (mine << 16) | mf_from_upper_half(mine);
+                    // (a ray that is not ordinary has its list marked as overflowed and asks for nothing here)
+                    const unsigned any = mf_wave_or(own[t] ? full : 0u);
+                    if (l == 0) need[t][0] = any; else need[t][1] = any;
+                    if (CULL) tiles_done++;
+                }
+            }
+        }
         for (int g = g_begin; g < g_end; g++) {
+            const unsigned bit = 0x80000000u >> (g & 31);
+            bool want[MF_TILES], any_want = false;
+#pragma unroll
+            for (int t = 0; t < MF_TILES; t++) { want[t] = ((g < 32 ? need[t][0] : need[t][1]) & bit) != 0u; any_want |= want[t]; }
+            if (!any_want) continue;
             const uint4 f = mf_lds[g * MF_GROUP_WORDS + lane];
 #pragma unroll
             for (int t = 0; t < MF_TILES; t++) {
+                if (!want[t]) continue;
                 f32x16 hb, nn;
                 mf_products(f, rf[t], hb, nn);
                 consume(t, g, hb, nn);
+                if (CULL) tiles_done++;
             }
         }
         if (!SLICED) {
@@ -259,9 +300,11 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
     }
 }
 
-// Same contract as broad_kernel: for every queued ray the non-zero 32-record keep masks, appended to its list.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
+// Same contract as broad_kernel: for every queued ray the non-zero 32-record keep masks, appended to its list (an entry
+// names a group of the table's own record order, see mf_build_table).  frags: per window its groups' fragments followed
+// by the fragments of its group records; CULL: test the group records first (the camera rays' round).
+template <int BLOCK, bool CULL>
+__global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
     extern __shared__ uint4 mf_lds[];
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
@@ -269,6 +312,7 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, con
     constexpr unsigned per_block = (BLOCK / 64) * MF_TILES * 32;
     const unsigned nbatches = (count + per_block - 1) / per_block;
     const int n_windows = (n_groups + win_groups - 1) / win_groups;
+    const int win_words = (win_groups + (win_groups + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_WORDS;
     // fewer batches than workgroups: the groups of the (single) window are shared out in slices, see broad_kernel
     unsigned slices = 1;
     if (n_windows == 1 && nbatches < gridDim.x) {
@@ -276,19 +320,33 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_kernel(const WfParams w, con
         if (slices > (unsigned)n_groups) slices = (unsigned)n_groups;
     }
     if (blockIdx.x >= nbatches * slices) return;
+    // (tile, group) products of this lane's wave (the same in all its lanes), counted in the launches that test group
+    // records first -- elsewhere the number follows from the ray count; summed per workgroup: one atomic per wave on the
+    // one counter is a queue of microseconds at the end of a short launch
+    unsigned tiles_done = 0;
+    __shared__ unsigned tiles_wg;
+    if (threadIdx.x == 0) tiles_wg = 0u;
     for (int win = 0; win < n_windows; win++) {
         const int g0 = win * win_groups;
         const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
+        const int staged = (gn + (gn + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_WORDS;
         if (win > 0) __syncthreads();
-        for (int i = threadIdx.x; i < gn * MF_GROUP_WORDS; i += BLOCK) mf_lds[i] = frags[(size_t)g0 * MF_GROUP_WORDS + i];
+        for (int i = threadIdx.x; i < staged; i += BLOCK) mf_lds[i] = frags[(size_t)win * win_words + i];
         __syncthreads();
         if (slices > 1) {
             const unsigned slice = blockIdx.x / nbatches;
-            mf_scan_window<BLOCK, true>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x % nbatches, nbatches, g0,
-                                        (int)((unsigned)gn * slice / slices), (int)((unsigned)gn * (slice + 1) / slices), true);
+            mf_scan_window<BLOCK, true, false>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x % nbatches, nbatches, g0,
+                                               (int)((unsigned)gn * slice / slices), (int)((unsigned)gn * (slice + 1) / slices), true, gn, tiles_done);
+        } else if (CULL) {
+            mf_scan_window<BLOCK, false, true>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0, gn, tiles_done);
         } else {
-            mf_scan_window<BLOCK, false>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0);
+            mf_scan_window<BLOCK, false, false>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0, gn, tiles_done);
         }
+    }
+    if (CULL) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(&tiles_wg, tiles_done);
+        __syncthreads();
+        if (threadIdx.x == 0 && tiles_wg) atomicAdd((unsigned long long*)(w.kp.ctrl + 14), (unsigned long long)tiles_wg);
     }
 }
 

@@ -14,6 +14,7 @@ namespace {
 // results are merged with get_intersection's order-independent acceptance (consider_q).
 constexpr unsigned HEAVY_WORDS = 6, HEAVY_BITS = 48;   // shared out: lists of more than 6 mask words with more than 48 records
 
+template <bool PLACES>
 DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
     const int lane = threadIdx.x & 63;
     Hit h;
@@ -55,10 +56,9 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
             while (m) {
                 const int k = __clz((int)m);
                 m &= ~(0x80000000u >> k);
-                const int idx = (int)ent.x * BROAD_GROUP + k;
                 // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
-                // included: indices past the list are never dereferenced
-                if (idx < w.kp.n_prims) narrow_one(idx, o, d, w.kp, h);
+                // included: places past the list are never dereferenced
+                narrow_place<PLACES>((int)ent.x * BROAD_GROUP + k, o, d, w.kp, h);
             }
         }
 #if DIAG_TWICE_CAND
@@ -94,7 +94,8 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
 // FIRST: the round of the camera rays.  Queue position = pixel slot and the path state is the start state, which the
 // lane rebuilds from the pixel index (the same operations as init_kernel, hence the same bits) instead of reading it:
 // init_kernel then writes 36 bytes per pixel instead of 152 and this round reads none of them back.
-template <bool FIRST>
+// PLACES: the candidate lists name places of the matrix-core scan's own record order (narrow_place).
+template <bool FIRST, bool PLACES>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w) {
     extern __shared__ double alw[];
     const unsigned count = w.counts[w.iter];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             ro = dmk(p0.x, p0.y, p1.x);
             rd = dmk(p1.y, p2.x, p2.y);
         }
-        const Hit h = find_hit(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
+        const Hit h = find_hit<PLACES>(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         if (live) {
             if (FIRST) {

@@ -189,22 +189,42 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     return true;
 }
 
-// narrow phase on one candidate: the reference's double-precision test
+// narrow phase on one candidate: the reference's double-precision test.
+// The solid's first 32 bytes (point a, radius) have been read: a number in the radius word means a sphere, with no
+// further read (the table holds a NaN radius for planes and faces; a sphere whose own radius is NaN takes the long
+// way round and is still tested as a sphere).
+DEV d3 narrow_point_from(int idx, d3 a, double radius, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
+    if (radius == radius) return sphere_point(a, radius, o, d);
+    const PrimD* pr = prims + idx;
+    const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
+    const double2 p01 = ld2(pr->a), p2r = ld2(pr->a + 2);
+    const d3 pa = dmk(p01.x, p01.y, p2r.x);
+    if (ids.x == RT_KIND_SPHERE) return sphere_point(pa, p2r.y, o, d);
+    const double2 n01 = ld2(pr->n), n2p = ld2(pr->n + 2);
+    const d3 n = dmk(n01.x, n01.y, n2p.x);
+    if (ids.x == RT_KIND_PLANE) return plane_point(pa, n, o, d);
+    return face_point(pa, n, pr->vcnt, verts + ids.w, o, d);
+}
 DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
     const PrimD* pr = prims + idx;
     const double2 a01 = ld2(pr->a), a2r = ld2(pr->a + 2);
-    const d3 a = dmk(a01.x, a01.y, a2r.x);
-    // the table holds a NaN radius for planes and faces: a number means a sphere, with no further read (a sphere
-    // whose own radius is NaN takes the long way round and is still tested as a sphere)
-    if (a2r.y == a2r.y) return sphere_point(a, a2r.y, o, d);
-    const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
-    if (ids.x == RT_KIND_SPHERE) return sphere_point(a, a2r.y, o, d);
-    const double2 n01 = ld2(pr->n), n2p = ld2(pr->n + 2);
-    const d3 n = dmk(n01.x, n01.y, n2p.x);
-    if (ids.x == RT_KIND_PLANE) return plane_point(a, n, o, d);
-    return face_point(a, n, pr->vcnt, verts + ids.w, o, d);
+    return narrow_point_from(idx, dmk(a01.x, a01.y, a2r.x), a2r.y, o, d, prims, verts);
 }
 DEV void narrow_one(int idx, d3 o, d3 d, const KParams& kp, Hit& h) { consider(narrow_point(idx, o, d, kp.prims, kp.verts), idx, o, h); }
+
+// A candidate named by its place in a list's record order.  Lists of the matrix-core scan name places of that scan's
+// own order: the solid's first 32 bytes come from a compact copy in that order (kp.mf_cand) and its file index from
+// kp.mf_perm, two reads that do not wait for one another; places that hold no solid read as a NaN radius and an index
+// past the list (PLACES).  Other lists name file indices (places past the list are padding and are not read).
+template <bool PLACES>
+DEV void narrow_place(int place, d3 o, d3 d, const KParams& kp, Hit& h) {
+    if (!PLACES) { if (place < kp.n_prims) narrow_one(place, o, d, kp, h); return; }
+    const double* c = kp.mf_cand + 4 * (size_t)place;
+    const int idx = (int)kp.mf_perm[place];
+    const double2 a01 = ld2(c), a2r = ld2(c + 2);
+    if (!(a2r.y == a2r.y) && idx >= kp.n_prims) return;
+    consider(narrow_point_from(idx, dmk(a01.x, a01.y, a2r.x), a2r.y, o, d, kp.prims, kp.verts), idx, o, h);
+}
 
 // Exact test of every "always" solid, read from `tab` (LDS or global) at wave-uniform addresses.  The table holds first
 // n_box "box" entries of ALW_BOX doubles, then the others: ALW_HEAD doubles (kind, file index, vertex count, -, point[3],

@@ -58,6 +58,9 @@ struct KParams {
     int max_verts;           // bounce-stack entries available per path (<= RT_MAXV)
     float cmax;              // max |C - T| + R over finite bounding spheres
     int wide;                // ray records with the wide error bounds (the broad phase runs on the matrix cores)
+    const unsigned* mf_perm; // candidate lists name places of broad_mfma_kernel's record order: place -> file index (null: lists
+                             // name file indices)
+    const double* mf_cand;   // [places][4]: (point a, radius) of the solid at a place, NaN radius for a plane, a face or no solid
     double T[3];             // translation applied before rounding coordinates to float
     const float4* records;
     const ChunkDesc* chunks;
@@ -71,7 +74,7 @@ struct KParams {
     double* rgb;
     int* hit_ids;
     unsigned long long* stream_rays;
-    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64), [6] rays whose candidate list overflowed
+    unsigned* ctrl;          // [0] queue head, [1] error bits, [2..3] rays (u64), [4..5] candidates (u64), [6] rays whose candidate list overflowed, [14..15] (tile, group) products of broad_mfma_kernel (u64)
 };
 
 }  // namespace

@@ -11,7 +11,7 @@ for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.wavefront_size', t, re.S):
     g=lambda k: re.search(k+r':\s+(\d+)', b).group(1)
     print(name[:60], 'vgpr', g(r'\.vgpr_count'), 'vspill', g(r'\.vgpr_spill_count'), 'sgpr', g(r'\.sgpr_count'), 'sspill', g(r'\.sgpr_spill_count'), 'scratch', g(r'\.private_segment_fixed_size'))
 lines=t.split('\n')
-st=[i for i,l in enumerate(lines) if l.startswith('_ZN12_GLOBAL__N_112shade_kernelILb0EEEvNS_8WfParamsE:')][0]
+st=[i for i,l in enumerate(lines) if l.startswith('_ZN12_GLOBAL__N_112shade_kernelILb0ELb0EEEvNS_8WfParamsE:')][0]
 en=[i for i,l in enumerate(lines) if i>st and l.startswith('.Lfunc_end')][0]
 n=sum(1 for l in lines[st:en] if l.strip() and not l.strip().startswith((';','.')) and not l.strip().endswith(':'))
 print('shade static instrs', n)
