@@ -78,9 +78,10 @@ def measured_traffic(kernel_prefix, key="bytes_per_frame"):
     SQ_INSTS_VALU count; None when no such profile is present."""
     try:
         k = json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["kernels"]
-        for name, v in k.items():
-            if name.startswith(kernel_prefix):
-                return v.get(key)
+        vals = [v.get(key) for name, v in k.items() if name.startswith(kernel_prefix + "<") or name == kernel_prefix]
+        vals = [v for v in vals if v is not None]
+        if vals:
+            return float(sum(vals))          # every instantiation of the kernel (template arguments in the name)
     except (OSError, KeyError, ValueError):
         pass
     return None
