@@ -220,6 +220,29 @@ def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
     assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
 
 
+def test_reordered_table_with_unbounded_records_matches_oracle(renderer):
+    """More planes than the always-tested table takes (64): the rest stay records of the scan that every ray keeps, here
+    in a table that is in its own (Morton) order -- 320 spheres, one path per pixel -- with the group-record pass on."""
+    import random
+    rng = random.Random(7)
+    objs = synth._room(2, 7)
+    for i in range(70):                                # parallel planes behind the back wall: tested, never the closest hit
+        objs.append({"shape": "plane", "is_light": False, "point": [0, 0, -100.0 - i], "normal": [0, 0, 1],
+                     "diffuse1": [0.5, 0.5, 0.5], "diffuse2": [0.4, 0.4, 0.4], "specular1": [0, 0, 0], "specular2": [0, 0, 0],
+                     "specular_exp": 1, "refraction_index": 0})
+    objs += synth._lattice_objects(rng, 8, 8, 5, 320, 0.05, 0.0)
+    header = {"num_threads": 4, "num_objs": len(objs), "exposure": 1, "num_blurs": 0, "paths_per_pixel": 1, "max_ray_depth": 3,
+              "scale": 768 / 40.0, "width": 768, "height": 432, "lens_radius": 1.0, "focal_length": 60}
+    sc = S.loads(S.dumps(header, objs))
+    renderer.set_option(api.OPT_OVERLAP, 1)           # one queue of 331 776 rays: more batches than workgroups, no slices
+    try:
+        g, _ = _compare(renderer, sc, "320 spheres + 78 planes")
+        t = renderer.timing()
+    finally:
+        renderer.set_option(api.OPT_OVERLAP, 2)
+    assert t["broad_tiles"] > 0 and t["broad_records"] % 32 == 0 and t["broad_records"] >= 320 + 14
+
+
 def test_moved_camera_matches_oracle(renderer, golden_dir):
     """Header extension "camera": the device and the oracle read the same three parameters (the reference's constant
     (0,0,40) is their default); no reference output exists for a moved camera, so this case is pinned by the oracle only."""
