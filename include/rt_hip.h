@@ -296,6 +296,14 @@ int rt_face_bound(int n_verts, const double* verts, const double* normal, double
  * (never / always kept record) becomes -/+ 65504. */
 int rt_mfma_record_pieces(const double* record, double cmax, double* scale, double* pieces);
 
+/* Host-only self-test (no GPU call): the record order of broad_mfma_kernel's table for n bounding spheres (T = 0) and the
+ * bounding spheres of its groups of 32.  radii[i] = -1: a solid that is never kept (left out of a reordered table), any
+ * other negative radius: an unbounded solid.  reorder = 0: file order.  perm[k] (k < 32 * groups): the index of the solid at
+ * place k, 0x7fffffff where a place holds none.  group_spheres[4 g ..]: centre and radius of group g's sphere (radius -1:
+ * empty group, +inf: the group holds an unbounded solid).  Returns the number of groups, < 0 on error (too small buffers). */
+int rt_mfma_table_order(int n, const double* centres, const double* radii, int reorder, uint32_t* perm, int perm_cap,
+                        double* group_spheres, int group_cap);
+
 /* Self-test of the broad phase on the matrix cores: every one of n_rays rays against every one of n_rec bounding spheres,
  * evaluated exactly as broad_mfma_kernel does.  masks: uint32[n_rays * ceil(n_rec / 32)] (HOST); bit 31 - k of
  * masks[ray * groups + g] is set iff record 32 g + k is kept for the ray. */

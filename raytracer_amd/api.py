@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces",
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces", "rt_mfma_table_order",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
            "rt_multi_render_image", "rt_multi_last_ms", "rt_multi_last_error", "rt_gather_source_row")
 
@@ -119,6 +119,8 @@ def load_library(path: str = LIB_PATH):
     l.rt_multi_last_error.argtypes = [C.c_void_p]
     l.rt_gather_source_row.restype = C.c_int
     l.rt_gather_source_row.argtypes = [C.c_int] * 5
+    l.rt_mfma_table_order.restype = C.c_int
+    l.rt_mfma_table_order.argtypes = [C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint32), C.c_int, dp, C.c_int]
     l.rt_mfma_record_pieces.restype = C.c_int
     l.rt_mfma_record_pieces.argtypes = [dp, C.c_double, C.POINTER(C.c_double), dp]
     l.rt_face_bound.restype = C.c_int
@@ -138,6 +140,20 @@ def face_bound(verts, normal):
     if rc < 0:
         raise RtError(rc, "rt_face_bound: bad argument")
     return (c, float(r.value)) if rc == 1 else None
+
+
+def mfma_table_order(centres, radii, reorder=True):
+    """(perm[32 * groups], group_spheres[groups][4]) of the matrix-core scan's table for these bounding spheres.  Host only."""
+    c = np.ascontiguousarray(centres, dtype=np.float64).reshape(-1, 3)
+    r = np.ascontiguousarray(radii, dtype=np.float64)
+    cap = (len(c) // 32 + 2)
+    perm = np.zeros(cap * 32, dtype=np.uint32)
+    gs = np.zeros((cap, 4))
+    n = load_library().rt_mfma_table_order(len(c), _dp(c), _dp(r), 1 if reorder else 0,
+                                           perm.ctypes.data_as(C.POINTER(C.c_uint32)), len(perm), _dp(gs), cap)
+    if n < 0:
+        raise RtError(n, "rt_mfma_table_order: bad argument")
+    return perm[: n * 32].copy(), gs[:n].copy()
 
 
 def mfma_record_pieces(record, cmax):

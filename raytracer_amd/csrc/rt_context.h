@@ -485,6 +485,7 @@ struct MfTable {
     float scale = 1.0f;
     double cmax = 0.0;           // largest extent |c| + R over records and group records
     bool reordered = false;      // false: file order, perm is the identity (places are file indices)
+    std::vector<float> group_records;   // (centre, R^2 - |c|^2) of every group's bounding sphere; -inf: empty group, +inf: holds an unbounded record
 };
 inline unsigned mf_spread10(unsigned v) {          // 10 bits -> every third bit
     v &= 0x3ffu;
@@ -560,6 +561,7 @@ MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, 
         if (ext > t.cmax) t.cmax = ext;
     }
     t.scale = mf_scale_for((float)(t.cmax * (1.0 + 1e-6)));
+    t.group_records = grp;
     for (int w = 0; w < t.n_windows; w++) {
         const int g0 = w * t.win_groups, gn = std::min(t.win_groups, t.n_groups - g0);
         for (int g = g0; g < g0 + gn; g++)

@@ -180,6 +180,31 @@ int rt_face_bound(int n_verts, const double* verts, const double* normal, double
     return face_bound(verts, n_verts, normal, centre, radius) ? 1 : 0;
 }
 
+int rt_mfma_table_order(int n, const double* centres, const double* radii, int reorder, uint32_t* perm, int perm_cap,
+                        double* group_spheres, int group_cap) {
+    if (n < 0 || !centres || !radii || !perm || !group_spheres) return RT_ERR_ARG;
+    std::vector<float> rec((size_t)(n > 0 ? n : 1) * 4);
+    double cmax = 0;
+    for (int i = 0; i < n; i++) {
+        float* r4 = &rec[4 * (size_t)i];
+        if (radii[i] == -1.0) { r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = -INFINITY; continue; }      // never kept (always-tested solid)
+        if (radii[i] < 0.0) { r4[0] = r4[1] = r4[2] = 0.0f; r4[3] = INFINITY; continue; }         // unbounded
+        const double ext = make_record(centres + 3 * (size_t)i, radii[i], r4);
+        if (ext > cmax) cmax = ext;
+    }
+    const MfTable t = mf_build_table(rec.data(), n, cmax, reorder != 0);
+    if ((int)t.perm.size() > perm_cap || t.n_groups > group_cap) return RT_ERR_ARG;
+    for (size_t k = 0; k < t.perm.size(); k++) perm[k] = t.perm[k];
+    for (int g = 0; g < t.n_groups; g++) {
+        const float* gr = &t.group_records[4 * (size_t)g];
+        double* o = group_spheres + 4 * (size_t)g;
+        o[0] = gr[0]; o[1] = gr[1]; o[2] = gr[2];
+        if (!(fabsf(gr[3]) <= 3.0e38f)) o[3] = gr[3] < 0 ? -1.0 : INFINITY;
+        else o[3] = sqrt(fmax(0.0, (double)gr[3] + (double)gr[0] * gr[0] + (double)gr[1] * gr[1] + (double)gr[2] * gr[2]));
+    }
+    return t.n_groups;
+}
+
 int rt_mfma_record_pieces(const double* record, double cmax, double* scale, double* pieces) {
     if (!record || !scale || !pieces) return RT_ERR_ARG;
     const float s = mf_scale_for((float)cmax);

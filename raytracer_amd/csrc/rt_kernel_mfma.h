@@ -40,6 +40,7 @@ constexpr int MF_BLOCK = 512;                 // threads per workgroup of broad_
 constexpr int MF_GROUP_BYTES = 1024;          // one fragment x 64 lanes x 16 bytes per group of 32 records
 constexpr int MF_GROUP_WORDS = MF_GROUP_BYTES / 16;
 constexpr int MF_WINDOW_GROUPS = 64;          // most groups per LDS window (64 KiB: two workgroups per CU)
+static_assert(MF_WINDOW_GROUPS <= 64, "a tile keeps its window's group mask in two 32-bit words");
 constexpr float MF_RANGE = 60000.0f;          // scaled ray constants must stay below this (f16 ends at 65504)
 
 // ---- host side: the pieces of the records -------------------------------------------------------

@@ -292,6 +292,44 @@ def test_matrix_core_record_pieces_are_f16_and_round_towards_keep():
     assert tuple(p[3]) == (65504.0, 0.0)
 
 
+def test_matrix_core_table_order_and_group_spheres():
+    """The scan's own record order: a permutation of the solids that can be kept (never-kept ones left out, unbounded ones
+    last), neighbours in space side by side, and every group's sphere holds its members' spheres."""
+    rng = np.random.default_rng(9)
+    n = 1000
+    c = rng.uniform(-30, 30, (n, 3))
+    r = rng.uniform(0.1, 1.5, n)
+    never = rng.random(n) < 0.03
+    unb = (rng.random(n) < 0.01) & ~never
+    r[never] = -1.0
+    r[unb] = -2.0
+    perm, gs = api.mfma_table_order(c, r, reorder=True)
+    NONE = 0x7fffffff
+    used = perm[perm != NONE]
+    assert sorted(used.tolist()) == sorted(np.flatnonzero(~never).tolist())
+    assert len(perm) % 32 == 0 and len(perm) - len(used) < 32
+    n_b = int((~never & ~unb).sum())
+    assert set(used[n_b:].tolist()) == set(np.flatnonzero(unb).tolist())          # unbounded ones at the end
+    spread_sorted, spread_file = [], []
+    for g in range(len(gs)):
+        m = perm[32 * g: 32 * g + 32]
+        m = m[m != NONE]
+        if len(m) == 0:
+            assert gs[g, 3] == -1.0
+            continue
+        if unb[m].any():
+            assert np.isinf(gs[g, 3])
+            continue
+        d = np.linalg.norm(c[m] - gs[g, :3], axis=1) + r[m]
+        assert (d <= gs[g, 3] * (1 + 1e-9)).all()
+        spread_sorted.append(gs[g, 3])
+    # file order of random points: every group spans the scene; Morton order: a fraction of it
+    _, gs_file = api.mfma_table_order(c, np.where(never | unb, 0.5, r), reorder=False)
+    assert np.mean(spread_sorted) < 0.6 * np.mean(gs_file[:, 3])
+    perm_f, _ = api.mfma_table_order(c, r, reorder=False)
+    assert (perm_f[:n] == np.arange(n)).all() and (perm_f[n:] == NONE).all()
+
+
 def test_gather_source_row_matches_the_partition():
     """rt_gather_source_row (host arithmetic of the in-library gather) against the packing order of the partition: rank r's
     buffer holds its rows in ascending order, buffers are stacked by rank with pad_rows rows each."""
