@@ -30,6 +30,7 @@ struct rt_context {
     int mf_win_groups = 0, mf_windows = 0;        //   groups per LDS window, windows
     bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
     bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
+    bool mf_binned = true;                        //   rounds after the camera rays': the binned scan (RT_MFMA_BINNED=0: plain)
     unsigned* d_mf_perm = nullptr;                //   place in the table's order -> file index of the solid
     double* d_mf_cand = nullptr;                  //   place -> (point a, radius) of the solid, for the exact phase
     void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;
@@ -527,7 +528,9 @@ MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, 
     }
     while (t.perm.empty() || t.perm.size() % BROAD_GROUP) t.perm.push_back(NONE);
     t.n_groups = (int)(t.perm.size() / BROAD_GROUP);
-    t.n_windows = (t.n_groups + MF_WINDOW_GROUPS - 1) / MF_WINDOW_GROUPS;
+    // a table in its own order is also scanned by the binned kernel, whose windows hold at most MFB_GROUPS groups
+    const int max_win = reorder ? MFB_GROUPS : MF_WINDOW_GROUPS;
+    t.n_windows = (t.n_groups + max_win - 1) / max_win;
     t.win_groups = (t.n_groups + t.n_windows - 1) / t.n_windows;
     // records in table order, and the group records
     std::vector<float> rec(t.perm.size() * 4), grp((size_t)t.n_groups * 4);

@@ -121,6 +121,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
+    if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
     if (const char* e = getenv("RT_BROAD_MFMA")) h->broad_mfma = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
@@ -638,10 +639,16 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     // one LDS window: its groups' fragments and those of its group records
     const int mf_win_groups = h->mf_win_groups;
     const size_t mfma_lds = (size_t)(mf_win_groups + (mf_win_groups + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_BYTES;
+    // the binned scan: 1024 threads, one workgroup per CU (its LDS: the window, 512 rays' fragments, the groups' ray lists)
+    constexpr int MFB_BLOCK = 1024, MFB_RAYS = MFB_BLOCK / 2;
+    const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)MFB_RAYS * 64 + (size_t)MFB_GROUPS * MFB_RAYS * 2 +
+                              (size_t)MFB_RAYS * 4 + MFB_GROUPS * 4 + 16;
     unsigned mgrid = 1, mgrid_cull = 1;
     if (use_mfma) {
         e = mfma_grid<MF_BLOCK, false>(h, mfma_lds, &mgrid);
         if (e == hipSuccess && h->mf_reordered) e = mfma_grid<MF_BLOCK, true>(h, mfma_lds, &mgrid_cull);
+        if (e == hipSuccess && h->mf_reordered && h->mf_binned)
+            e = hipFuncSetAttribute((const void*)broad_mfma_binned_kernel<MFB_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)binned_lds);
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
         for (int p = 0; p < nsub; p++) { wp[p].kp.wide = 1; wp[p].kp.mf_perm = h->d_mf_perm; wp[p].kp.mf_cand = h->d_mf_cand; }
     }
@@ -702,6 +709,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     // the camera rays' round of a table in its own order asks the group records first
                     if (it == 0 && h->mf_reordered)
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
+                    else if (h->mf_reordered && h->mf_binned)
+                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     else
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     e = hipGetLastError();

@@ -351,6 +351,135 @@ __global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, 
     }
 }
 
+// ---- the scan for rays that do not run side by side: binned by group -----------------------------------------------
+// A ray's line touches the bounding spheres of few groups (C3: 5 of 32), but the 32 rays of a tile of a later round
+// point every way and together touch them all, so asking the group records per tile drops nothing there.  This kernel
+// asks them per RAY and then turns the work round: a workgroup takes 32 rays per wave (512 with 16 waves), every ray is
+// tested against the window's group records and entered in the LDS list of each group it keeps; then the waves take
+// (group, 32 listed rays) items in turn -- the rays' fragments come back out of LDS by the list -- and only
+// these products are computed.  A kept word goes to its ray's list through a per-ray counter in LDS; the lists' order
+// is that of arrival (as with the sliced scan).  Needs windows of at most 32 groups (one group-record fragment).
+constexpr int MFB_GROUPS = 32;                 // groups per window for this kernel
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
+    extern __shared__ uint4 mf_lds[];
+    constexpr int NW = BLOCK / 64, RAYS = NW * 32;
+    constexpr unsigned SKIP = 0xffffffffu;
+    const unsigned count = w.counts[w.iter];
+    if (count == 0) return;
+    unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
+    const unsigned nbatches = (count + RAYS - 1) / RAYS;
+    if (blockIdx.x >= nbatches) return;
+    const int n_windows = (n_groups + win_groups - 1) / win_groups;
+    const int win_words = (win_groups + 1) * MF_GROUP_WORDS;
+    // LDS: the window's fragments (groups, then the group records), the rays' fragments [ray][half][q0, q1], the groups'
+    // ray lists, the rays' list lengths, the groups' list lengths
+    uint4* const gfr = mf_lds;
+    uint4* const rayf = gfr + win_words;
+    unsigned short* const lists = (unsigned short*)(rayf + RAYS * 4);
+    unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * RAYS);
+    unsigned* const gcount = rcnt + RAYS;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    const size_t cstride = w.slots;
+    for (int win = 0; win < n_windows; win++) {
+        const int g0 = win * win_groups;
+        const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
+        __syncthreads();
+        for (int i = threadIdx.x; i < (gn + 1) * MF_GROUP_WORDS; i += BLOCK) gfr[i] = frags[(size_t)win * win_words + i];
+        if (threadIdx.x < MFB_GROUPS) gcount[threadIdx.x] = 0u;
+        for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+            __syncthreads();                                   // staging / the previous pass is over
+            // ---- every wave: its 32 rays' fragments into LDS, their group masks, the groups' lists
+            const unsigned local = (unsigned)(wv * 32 + r);
+            const unsigned pos = batch * RAYS + local;
+            const bool valid = pos < count;
+            const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+            const float4 ra = valid ? w.rec[0][pos] : none, rb = valid ? w.rec[1][pos] : none;
+            const bool ordinary = mf_ordinary(ra, rb, scale);
+            const RayFrag rf = mf_ray_frag(ra, rb, scale, h, ordinary);
+            F16Pack p0, p1;
+            p0.v = rf.q0; p1.v = rf.q1;
+            rayf[local * 4 + h * 2 + 0] = p0.u;
+            rayf[local * 4 + h * 2 + 1] = p1.u;
+            const bool own = valid && h == 0 && ordinary;
+            if (h == 0) {
+                unsigned n0 = SKIP;                            // no ray here, or one whose list is marked as overflowed
+                if (valid && !ordinary) { if (win == 0) cand_cnt[pos] = WF_OVERFLOW; }
+                else if (valid) {
+                    n0 = 0u;
+                    if (win > 0) { n0 = cand_cnt[pos]; if (n0 > (unsigned)WF_CAND_CAP) n0 = (unsigned)WF_CAND_CAP + 1u; }
+                }
+                rcnt[local] = n0;
+            }
+            unsigned gm;
+            {
+                f32x16 hb, nn;
+                mf_products(gfr[gn * MF_GROUP_WORDS + lane], rf, hb, nn);
+                const unsigned mine = mf_signs(hb, nn);
+                const unsigned full = (mine << 16) | mf_from_upper_half(mine);
+                gm = own ? full : 0u;
+            }
+            // group k's rays of this wave as a ballot word, kept by lane k; one LDS atomic (all 32 groups at once)
+            // reserves the wave's places in the groups' lists; then every ray enters itself for each of its bits
+            unsigned bw = 0;                                   // lane k < 32: bit r set iff ray r of the wave keeps group k
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const unsigned b = (unsigned)__ballot((gm & (0x80000000u >> k)) != 0u);     // (upper lane half: gm = 0)
+                if (lane == k) bw = b;
+            }
+            unsigned base = 0;
+            if (lane < 32 && bw != 0u) base = atomicAdd(&gcount[lane], (unsigned)__popc(bw));
+            unsigned mine_bits = gm;
+            while (__ballot(mine_bits != 0u)) {                // whole waves: a lane another lane reads from must be running
+                const bool go = mine_bits != 0u;
+                const int k = go ? __builtin_clz(mine_bits) : 0;
+                mine_bits &= ~(0x80000000u >> k);              // (clears bit 31 of a zero word: still zero)
+                const unsigned bk = (unsigned)__shfl((int)bw, k, 64), basek = (unsigned)__shfl((int)base, k, 64);
+                if (go) lists[k * RAYS + basek + (unsigned)__popc(bk & ((1u << r) - 1u))] = (unsigned short)local;
+            }
+            __syncthreads();                                   // the lists are complete
+            // ---- items (group, 32 listed rays): lane g < 32 holds group g's range of item numbers
+            unsigned cg = (lane < gn) ? gcount[lane] : 0u;
+            unsigned incl = (cg + 31u) >> 5;
+            for (int off = 1; off < 32; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
+                if ((lane & 31) >= off) incl += up;
+            }
+            const unsigned start = incl - ((cg + 31u) >> 5);
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+            for (unsigned item = (unsigned)wv; item < total; item += NW) {     // items cost the same: dealt out in turn
+                const unsigned long long in = __ballot(lane < 32 && start <= item && item < incl);
+                const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
+                const unsigned c = item - (unsigned)__builtin_amdgcn_readlane((int)start, g);
+                const unsigned n_in = (unsigned)__builtin_amdgcn_readlane((int)cg, g) - c * 32u;
+                const bool have = (unsigned)r < n_in;
+                const unsigned id = have ? (unsigned)lists[g * RAYS + c * 32u + (unsigned)r] : 0u;
+                RayFrag q;
+                F16Pack a0, a1;
+                a0.u = rayf[id * 4 + h * 2 + 0]; a1.u = rayf[id * 4 + h * 2 + 1];
+                if (!have) { a0.u = make_uint4(0u, 0u, 0u, 0u); a1.u = a0.u; }
+                q.q0 = a0.v; q.q1 = a1.v;
+                f32x16 hb, nn;
+                mf_products(gfr[g * MF_GROUP_WORDS + lane], q, hb, nn);
+                const unsigned mine = mf_signs(hb, nn);
+                const unsigned full = (mine << 16) | mf_from_upper_half(mine);
+                if (h == 0 && have && full != 0u) {
+                    const unsigned at = atomicAdd(&rcnt[id], 1u);
+                    if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + (batch * RAYS + id)] = make_uint2((unsigned)(g0 + g), full);
+                }
+            }
+            __syncthreads();                                   // every item is done
+            // ---- the rays' list lengths; the counters for the next pass
+            if (threadIdx.x < RAYS) {
+                const unsigned n1 = rcnt[threadIdx.x], p = batch * RAYS + threadIdx.x;
+                if (n1 != SKIP && p < count) cand_cnt[p] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
+            }
+            if (threadIdx.x < MFB_GROUPS) gcount[threadIdx.x] = 0u;
+        }
+    }
+}
+
 // self-test: keep masks of n_rays rays (records of broad_setup in ra/rb) against n_groups groups, masks[ray * n_groups + g]
 __global__ __launch_bounds__(64) void selftest_mfma_kernel(int n_rays, const float4* ra, const float4* rb, const uint4* frags, int n_groups, float scale, unsigned* masks) {
     const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;

@@ -7,7 +7,7 @@ import re
 t=open('/tmp/kinfo.s').read()
 for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.wavefront_size', t, re.S):
     name=m.group(1); b=m.group(2)
-    if 'shade' not in name and 'broad_kernelILi512' not in name and 'mfma' not in name and 'walk' not in name and 'init' not in name: continue
+    if 'shade' not in name and 'broad_kernelILi512' not in name and 'mfma' not in name and 'binned' not in name and 'walk' not in name and 'init' not in name: continue
     g=lambda k: re.search(k+r':\s+(\d+)', b).group(1)
     print(name[:60], 'vgpr', g(r'\.vgpr_count'), 'vspill', g(r'\.vgpr_spill_count'), 'sgpr', g(r'\.sgpr_count'), 'sspill', g(r'\.sgpr_spill_count'), 'scratch', g(r'\.private_segment_fixed_size'))
 lines=t.split('\n')
