@@ -639,10 +639,10 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     // one LDS window: its groups' fragments and those of its group records
     const int mf_win_groups = h->mf_win_groups;
     const size_t mfma_lds = (size_t)(mf_win_groups + (mf_win_groups + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_BYTES;
-    // the binned scan: 1024 threads, one workgroup per CU (its LDS: the window, 512 rays' fragments, the groups' ray lists)
+    // the binned scan: 1024 threads, two workgroups per CU (LDS: the window, 512 rays' fragments, the groups' ray lists)
     constexpr int MFB_BLOCK = 1024, MFB_RAYS = MFB_BLOCK / 2;
-    const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)MFB_RAYS * 64 + (size_t)MFB_GROUPS * MFB_RAYS * 2 +
-                              (size_t)MFB_RAYS * 4 + MFB_GROUPS * 4 + 16;
+    const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)MFB_RAYS * 64 + (size_t)MFB_GROUPS * MFB_LIST * 2 +
+                              (size_t)MFB_RAYS * 4 + 2 * MFB_GROUPS * 4;
     unsigned mgrid = 1, mgrid_cull = 1;
     if (use_mfma) {
         e = mfma_grid<MF_BLOCK, false>(h, mfma_lds, &mgrid);
@@ -710,7 +710,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     if (it == 0 && h->mf_reordered)
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     else if (h->mf_reordered && h->mf_binned)
-                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
+                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     else
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     e = hipGetLastError();

@@ -360,9 +360,10 @@ __global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, 
 // these products are computed.  A kept word goes to its ray's list through a per-ray counter in LDS; the lists' order
 // is that of arrival (as with the sliced scan).  Needs windows of at most 32 groups (one group-record fragment).
 constexpr int MFB_GROUPS = 32;                 // groups per window for this kernel
+constexpr int MFB_LIST = 192;                  // places in a group's ray list; a group more rays than that keep is scanned for all
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
+__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
     extern __shared__ uint4 mf_lds[];
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
     constexpr unsigned SKIP = 0xffffffffu;
@@ -374,22 +375,24 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_binned_kernel(const WfParams
     const int n_windows = (n_groups + win_groups - 1) / win_groups;
     const int win_words = (win_groups + 1) * MF_GROUP_WORDS;
     // LDS: the window's fragments (groups, then the group records), the rays' fragments [ray][half][q0, q1], the groups'
-    // ray lists, the rays' list lengths, the groups' list lengths
+    // ray lists, the rays' list lengths, the groups' list lengths (two copies, by pass parity)
     uint4* const gfr = mf_lds;
     uint4* const rayf = gfr + win_words;
     unsigned short* const lists = (unsigned short*)(rayf + RAYS * 4);
-    unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * RAYS);
-    unsigned* const gcount = rcnt + RAYS;
+    unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * MFB_LIST);
+    unsigned* const gcount2 = rcnt + RAYS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const size_t cstride = w.slots;
+    unsigned pass = 0;
     for (int win = 0; win < n_windows; win++) {
         const int g0 = win * win_groups;
         const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
-        __syncthreads();
+        __syncthreads();                                       // the previous window's last items are done
         for (int i = threadIdx.x; i < (gn + 1) * MF_GROUP_WORDS; i += BLOCK) gfr[i] = frags[(size_t)win * win_words + i];
-        if (threadIdx.x < MFB_GROUPS) gcount[threadIdx.x] = 0u;
-        for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
-            __syncthreads();                                   // staging / the previous pass is over
+        if (threadIdx.x < 2 * MFB_GROUPS) gcount2[threadIdx.x] = 0u;
+        __syncthreads();
+        for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x, pass++) {
+            unsigned* const gcount = gcount2 + (pass & 1u) * MFB_GROUPS;
             // ---- every wave: its 32 rays' fragments into LDS, their group masks, the groups' lists
             const unsigned local = (unsigned)(wv * 32 + r);
             const unsigned pos = batch * RAYS + local;
@@ -436,25 +439,33 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_binned_kernel(const WfParams
                 const int k = go ? __builtin_clz(mine_bits) : 0;
                 mine_bits &= ~(0x80000000u >> k);              // (clears bit 31 of a zero word: still zero)
                 const unsigned bk = (unsigned)__shfl((int)bw, k, 64), basek = (unsigned)__shfl((int)base, k, 64);
-                if (go) lists[k * RAYS + basek + (unsigned)__popc(bk & ((1u << r) - 1u))] = (unsigned short)local;
+                const unsigned place = basek + (unsigned)__popc(bk & ((1u << r) - 1u));
+                if (go && place < (unsigned)MFB_LIST) lists[k * MFB_LIST + place] = (unsigned short)local;
             }
             __syncthreads();                                   // the lists are complete
-            // ---- items (group, 32 listed rays): lane g < 32 holds group g's range of item numbers
-            unsigned cg = (lane < gn) ? gcount[lane] : 0u;
-            unsigned incl = (cg + 31u) >> 5;
+            // ---- items (group, 32 rays): lane g < 32 holds group g's range of item numbers.  A group whose list did
+            // not hold all its rays takes the pass's rays as they come (NW items), no list.
+            const unsigned cg = (lane < gn) ? gcount[lane] : 0u;
+            const bool dense = cg > (unsigned)MFB_LIST;
+            const unsigned chunks = dense ? (unsigned)NW : (cg + 31u) >> 5;
+            unsigned incl = chunks;
             for (int off = 1; off < 32; off <<= 1) {
                 const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
                 if ((lane & 31) >= off) incl += up;
             }
-            const unsigned start = incl - ((cg + 31u) >> 5);
+            const unsigned start = incl - chunks;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+            if (threadIdx.x < MFB_GROUPS) gcount2[((pass & 1u) ^ 1u) * MFB_GROUPS + threadIdx.x] = 0u;     // the next pass's counters
             for (unsigned item = (unsigned)wv; item < total; item += NW) {     // items cost the same: dealt out in turn
                 const unsigned long long in = __ballot(lane < 32 && start <= item && item < incl);
                 const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
                 const unsigned c = item - (unsigned)__builtin_amdgcn_readlane((int)start, g);
-                const unsigned n_in = (unsigned)__builtin_amdgcn_readlane((int)cg, g) - c * 32u;
+                const unsigned cgg = (unsigned)__builtin_amdgcn_readlane((int)cg, g);
+                const bool all_rays = cgg > (unsigned)MFB_LIST;
+                const unsigned n_in = all_rays ? 32u : cgg - c * 32u;
                 const bool have = (unsigned)r < n_in;
-                const unsigned id = have ? (unsigned)lists[g * RAYS + c * 32u + (unsigned)r] : 0u;
+                unsigned id = c * 32u + (unsigned)r;
+                if (!all_rays) id = have ? (unsigned)lists[g * MFB_LIST + id] : 0u;
                 RayFrag q;
                 F16Pack a0, a1;
                 a0.u = rayf[id * 4 + h * 2 + 0]; a1.u = rayf[id * 4 + h * 2 + 1];
@@ -464,18 +475,18 @@ __global__ __launch_bounds__(BLOCK) void broad_mfma_binned_kernel(const WfParams
                 mf_products(gfr[g * MF_GROUP_WORDS + lane], q, hb, nn);
                 const unsigned mine = mf_signs(hb, nn);
                 const unsigned full = (mine << 16) | mf_from_upper_half(mine);
-                if (h == 0 && have && full != 0u) {
+                // (a ray without a list of its own -- none here, not ordinary -- has zero fragments, but its rcnt says SKIP)
+                if (h == 0 && have && full != 0u && rcnt[id] != SKIP) {
                     const unsigned at = atomicAdd(&rcnt[id], 1u);
                     if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + (batch * RAYS + id)] = make_uint2((unsigned)(g0 + g), full);
                 }
             }
             __syncthreads();                                   // every item is done
-            // ---- the rays' list lengths; the counters for the next pass
-            if (threadIdx.x < RAYS) {
-                const unsigned n1 = rcnt[threadIdx.x], p = batch * RAYS + threadIdx.x;
-                if (n1 != SKIP && p < count) cand_cnt[p] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
+            // ---- the rays' list lengths, by the lanes that own the rays (they set the next pass's start values next)
+            if (h == 0) {
+                const unsigned n1 = rcnt[local];
+                if (n1 != SKIP) cand_cnt[pos] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
             }
-            if (threadIdx.x < MFB_GROUPS) gcount[threadIdx.x] = 0u;
         }
     }
 }
