@@ -31,6 +31,7 @@ struct rt_context {
     bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
     bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
     bool mf_binned = true;                        //   rounds after the camera rays': the binned scan (RT_MFMA_BINNED=0: plain)
+    int mf_list_cap = MFB_LIST;                   //   places used in a group's ray list (RT_MFMA_LIST: tests of the all-rays path)
     unsigned* d_mf_perm = nullptr;                //   place in the table's order -> file index of the solid
     double* d_mf_cand = nullptr;                  //   place -> (point a, radius) of the solid, for the exact phase
     void* d_always = nullptr; int n_always = 0, always_doubles = 0, n_box = 0;

@@ -122,6 +122,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
+    if (const char* e = getenv("RT_MFMA_LIST")) { const int v = atoi(e); if (v >= 0 && v <= MFB_LIST) h->mf_list_cap = v; }
     if (const char* e = getenv("RT_BROAD_MFMA")) h->broad_mfma = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
     *out = h;
@@ -710,7 +711,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     if (it == 0 && h->mf_reordered)
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     else if (h->mf_reordered && h->mf_binned)
-                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
+                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale, h->mf_list_cap);
                     else
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     e = hipGetLastError();

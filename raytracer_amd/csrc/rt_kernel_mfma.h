@@ -361,9 +361,10 @@ __global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, 
 // is that of arrival (as with the sliced scan).  Needs windows of at most 32 groups (one group-record fragment).
 constexpr int MFB_GROUPS = 32;                 // groups per window for this kernel
 constexpr int MFB_LIST = 192;                  // places in a group's ray list; a group more rays than that keep is scanned for all
+                                               // (list_cap <= MFB_LIST: the number in use, lower in tests of that path)
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale) {
+__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap) {
     extern __shared__ uint4 mf_lds[];
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
     constexpr unsigned SKIP = 0xffffffffu;
@@ -440,13 +441,13 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 mine_bits &= ~(0x80000000u >> k);              // (clears bit 31 of a zero word: still zero)
                 const unsigned bk = (unsigned)__shfl((int)bw, k, 64), basek = (unsigned)__shfl((int)base, k, 64);
                 const unsigned place = basek + (unsigned)__popc(bk & ((1u << r) - 1u));
-                if (go && place < (unsigned)MFB_LIST) lists[k * MFB_LIST + place] = (unsigned short)local;
+                if (go && place < (unsigned)list_cap) lists[k * MFB_LIST + place] = (unsigned short)local;
             }
             __syncthreads();                                   // the lists are complete
             // ---- items (group, 32 rays): lane g < 32 holds group g's range of item numbers.  A group whose list did
             // not hold all its rays takes the pass's rays as they come (NW items), no list.
             const unsigned cg = (lane < gn) ? gcount[lane] : 0u;
-            const bool dense = cg > (unsigned)MFB_LIST;
+            const bool dense = cg > (unsigned)list_cap;
             const unsigned chunks = dense ? (unsigned)NW : (cg + 31u) >> 5;
             unsigned incl = chunks;
             for (int off = 1; off < 32; off <<= 1) {
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
                 const unsigned c = item - (unsigned)__builtin_amdgcn_readlane((int)start, g);
                 const unsigned cgg = (unsigned)__builtin_amdgcn_readlane((int)cg, g);
-                const bool all_rays = cgg > (unsigned)MFB_LIST;
+                const bool all_rays = cgg > (unsigned)list_cap;
                 const unsigned n_in = all_rays ? 32u : cgg - c * 32u;
                 const bool have = (unsigned)r < n_in;
                 unsigned id = c * 32u + (unsigned)r;

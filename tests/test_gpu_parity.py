@@ -220,6 +220,25 @@ def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
     assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
 
 
+@pytest.mark.parametrize("env", [{"RT_MFMA_LIST": "0"}, {"RT_MFMA_LIST": "24"}, {"RT_MFMA_BINNED": "0"}])
+def test_binned_scan_variants_do_not_change_bits(renderer, monkeypatch, env):
+    """The scan of the later rounds lists every group's rays and computes only listed (group, rays) products.  A group
+    that more rays keep than its list holds is scanned for all rays of the pass instead: forced here for every group
+    (0 places) and for the busier ones (24), and compared with the default and with the plain scan, bit for bit."""
+    _, sc = synth.make("c3", width=640)
+    renderer.upload(sc)
+    a = renderer.render(want_hits=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = api.Renderer(0)
+    try:
+        other.upload(sc)
+        b = other.render(want_hits=True)
+    finally:
+        other.close()
+    assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
+
+
 def test_reordered_table_with_unbounded_records_matches_oracle(renderer):
     """More planes than the always-tested table takes (64): the rest stay records of the scan that every ray keeps, here
     in a table that is in its own (Morton) order -- 320 spheres, one path per pixel -- with the group-record pass on."""
