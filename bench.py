@@ -264,20 +264,17 @@ def main():
         kname = "broad_mfma_kernel" if on_mfma else "broad_kernel"
         pairs = tm["rays"] * padded
         if on_mfma:
-            # the table of the scan (without the always-tested solids when it is in its own order); the camera rays' round
-            # asks the groups' bounding spheres first and scans only the groups some ray of a tile can touch: its products
-            # are counted on the device, the other rounds test every ray against every record of the table
+            # the table of the scan (without the always-tested solids when it is in its own order); with the table in its own
+            # order the kernels ask the groups' bounding spheres first and compute only the products those leave: the
+            # device counts the (32 rays x 32 records) products it puts through the MFMAs
             padded = int(tm["broad_records"])
-            pairs = tm["rays"] * padded
-            if tm["broad_tiles"]:
-                camera_rays = api.rows_for_rank(H, args.tile_rows, rank, world) * W          # one path per pixel, or the table keeps file order
-                pairs = (tm["rays"] - camera_rays) * padded + int(tm["broad_tiles"]) * 1024
+            pairs = int(tm["broad_tiles"]) * 1024
             executed = MFMA_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
             executed_peak = F16_MFMA_PEAK_TFLOPS
             executed_basis = ("%d f16 MFMA FLOP x (ray, record) pairs put through the MFMAs (%d records in the table%s) / %s time, "
                               "against the dense f16 MFMA peak; beside it %d FP32 FLOP per pair on the vector ALU"
-                              % (MFMA_FLOP_PER_TEST, padded, "; camera rays' round: the groups its group-record pass leaves, counted on the device"
-                                 if tm["broad_tiles"] else "", kname, MFMA_VALU_FLOP_PER_TEST))
+                              % (MFMA_FLOP_PER_TEST, padded, "; products counted on the device: %.1f %% of rays x records"
+                                 % (100.0 * pairs / max(1, tm["rays"] * padded)), kname, MFMA_VALU_FLOP_PER_TEST))
         else:
             executed = EXECUTED_FLOP_PER_TEST * pairs / (broad_ms * 1e-3) / 1e12
             executed_peak = FP32_VALU_PEAK_TFLOPS

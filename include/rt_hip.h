@@ -100,8 +100,7 @@ typedef struct {
     uint64_t face_tests;
     uint64_t face_vert_tests;
     uint64_t overflow_rays; /* pipeline: rays with a long candidate list (more than 6 mask words), tested against every solid by their whole wave */
-    uint64_t broad_tiles;   /* matrix-core scan, launches that test group records first (the camera rays' round): */
-                            /* (32 rays x 32 records) products executed, group records included; 0 if there was none */
+    uint64_t broad_tiles;   /* matrix-core scan: (32 rays x 32 records) products executed, group records included */
     uint64_t broad_records; /* records of the matrix-core scan's table (a multiple of 32): what every other launch tests each ray against */
 } rt_timing;
 

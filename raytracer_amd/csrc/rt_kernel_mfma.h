@@ -278,6 +278,7 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
                 }
             }
         }
+        if (!CULL) tiles_done += (unsigned)(g_end - g_begin) * MF_TILES;      // every group for every tile
         for (int g = g_begin; g < g_end; g++) {
             const unsigned bit = 0x80000000u >> (g & 31);
             bool want[MF_TILES], any_want = false;
@@ -321,9 +322,8 @@ __global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, 
         if (slices > (unsigned)n_groups) slices = (unsigned)n_groups;
     }
     if (blockIdx.x >= nbatches * slices) return;
-    // (tile, group) products of this lane's wave (the same in all its lanes), counted in the launches that test group
-    // records first -- elsewhere the number follows from the ray count; summed per workgroup: one atomic per wave on the
-    // one counter is a queue of microseconds at the end of a short launch
+    // (tile, group) products of this lane's wave (the same in all its lanes); summed per workgroup: one atomic per wave
+    // on the one counter is a queue of microseconds at the end of a short launch
     unsigned tiles_done = 0;
     __shared__ unsigned tiles_wg;
     if (threadIdx.x == 0) tiles_wg = 0u;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK, 6) void broad_mfma_kernel(const WfParams w, 
             mf_scan_window<BLOCK, false, false>(w, mf_lds, scale, cand_cnt, count, nbatches, blockIdx.x, gridDim.x, g0, 0, gn, win == 0, gn, tiles_done);
         }
     }
-    if (CULL) {
+    {
         if ((threadIdx.x & 63) == 0) atomicAdd(&tiles_wg, tiles_done);
         __syncthreads();
         if (threadIdx.x == 0 && tiles_wg) atomicAdd((unsigned long long*)(w.kp.ctrl + 14), (unsigned long long)tiles_wg);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
     unsigned* const gcount2 = rcnt + RAYS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const size_t cstride = w.slots;
-    unsigned pass = 0;
+    unsigned pass = 0, tiles_done = 0;                     // (32 rays x 32 records) products of this wave
     for (int win = 0; win < n_windows; win++) {
         const int g0 = win * win_groups;
         const int gn = n_groups - g0 < win_groups ? n_groups - g0 : win_groups;
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const unsigned start = incl - chunks;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
             if (threadIdx.x < MFB_GROUPS) gcount2[((pass & 1u) ^ 1u) * MFB_GROUPS + threadIdx.x] = 0u;     // the next pass's counters
+            tiles_done += 1u + (total > (unsigned)wv ? (total - (unsigned)wv + NW - 1u) / NW : 0u);      // group records + this wave's items
             for (unsigned item = (unsigned)wv; item < total; item += NW) {     // items cost the same: dealt out in turn
                 const unsigned long long in = __ballot(lane < 32 && start <= item && item < incl);
                 const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
@@ -490,6 +491,14 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             }
         }
     }
+    // one atomic per workgroup on the product counter
+    __syncthreads();
+    unsigned* const tiles_wg = gcount2;
+    if (threadIdx.x == 0) *tiles_wg = 0u;
+    __syncthreads();
+    if (lane == 0) atomicAdd(tiles_wg, tiles_done);
+    __syncthreads();
+    if (threadIdx.x == 0 && *tiles_wg) atomicAdd((unsigned long long*)(w.kp.ctrl + 14), (unsigned long long)*tiles_wg);
 }
 
 // self-test: keep masks of n_rays rays (records of broad_setup in ra/rb) against n_groups groups, masks[ray * n_groups + g]

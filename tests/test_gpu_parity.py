@@ -197,17 +197,14 @@ def test_baseline_configs_reduced(renderer, cfg, width, kw):
 
 
 def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
-    """The camera rays' round of the matrix-core scan asks the bounding spheres of the 32-record groups first (table in
-    Morton order).  It must scan clearly fewer (tile, group) products than rays x groups and leave every output bit as it
-    is without the pass (RT_MFMA_CULL=0: file order, every group scanned)."""
+    """With its table in Morton order the matrix-core scan asks the bounding spheres of the 32-record groups first (per
+    tile in the camera rays' round, per ray afterwards).  It must compute clearly fewer (32 rays x 32 records) products
+    than rays x groups and leave every output bit as it is without that (RT_MFMA_CULL=0: file order, every group scanned)."""
     _, sc = synth.make("c3", width=960)
     renderer.upload(sc)
     a = renderer.render(want_hits=True)
     ta = renderer.timing()
     assert ta["broad_records"] == 1024 and ta["broad_tiles"] > 0          # 1024 spheres: the walls are not in the table
-    pixels = sc.width * sc.height
-    full = -(-pixels // 32) * (1024 // 32)
-    assert ta["broad_tiles"] < 0.6 * full, (ta["broad_tiles"], full)
     monkeypatch.setenv("RT_MFMA_CULL", "0")
     plain = api.Renderer(0)
     try:
@@ -216,7 +213,9 @@ def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
         tb = plain.timing()
     finally:
         plain.close()
-    assert tb["broad_tiles"] == 0 and tb["broad_records"] == 1056          # file order: 1031 solids padded to whole groups
+    assert tb["broad_records"] == 1056                                     # file order: 1031 solids padded to whole groups
+    # every ray against every group there; here the groups the group records leave: well under half the products
+    assert tb["broad_tiles"] >= a["rays"] // 32 * 33 and ta["broad_tiles"] < 0.5 * tb["broad_tiles"], (ta["broad_tiles"], tb["broad_tiles"])
     assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
 
 
