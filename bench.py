@@ -78,7 +78,7 @@ def measured_traffic(kernel_prefix, key="bytes_per_frame"):
     SQ_INSTS_VALU count; None when no such profile is present."""
     try:
         k = json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["kernels"]
-        vals = [v.get(key) for name, v in k.items() if name.startswith(kernel_prefix + "<") or name == kernel_prefix]
+        vals = [v.get(key) for name, v in k.items() if name.startswith(kernel_prefix)]
         vals = [v for v in vals if v is not None]
         if vals:
             return float(sum(vals))          # every instantiation of the kernel (template arguments in the name)
@@ -261,7 +261,8 @@ def main():
         kernel_achieved = flops_local / (broad_ms * 1e-3) / 1e12
         padded = (len(sc.prims) + 31) // 32 * 32
         on_mfma = os.environ.get("RT_BROAD_MFMA", "1") != "0"       # the library's default: the scan on the matrix cores
-        kname = "broad_mfma_kernel" if on_mfma else "broad_kernel"
+        kname = "broad_mfma_kernel + broad_mfma_binned_kernel" if on_mfma else "broad_kernel"
+        kprefix = "broad_mfma" if on_mfma else "broad_kernel"          # the kernels' names in the committed counter passes
         pairs = tm["rays"] * padded
         if on_mfma:
             # the table of the scan (without the always-tested solids when it is in its own order); with the table in its own
@@ -280,7 +281,7 @@ def main():
             executed_peak = FP32_VALU_PEAK_TFLOPS
             executed_basis = "15 FLOP x rays x padded records (%d) / broad_kernel time" % padded
         profiled = args.workload == "c3" and args.width is None and world == 1
-        valu = measured_traffic(kname, "valu_insts") if profiled else None
+        valu = measured_traffic(kprefix, "valu_insts") if profiled else None
         cnt = sc.counts()
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -303,7 +304,7 @@ def main():
                          # issue slots used: one VALU wave-instruction per SIMD every 2 cycles at 2.4 GHz is the peak
                          # (SQ_INSTS_VALU of the committed counter pass; it includes the MFMA instructions)
                          "valu_issue_frac": (valu / (1024 * 1.2e9 * broad_ms * 1e-3)) if valu else None,
-                         "traffic": measured_traffic(kname) if profiled else None,
+                         "traffic": measured_traffic(kprefix) if profiled else None,
                          "traffic_unit": "HBM bytes per frame (all %s launches), rocprofv3 FETCH_SIZE x2 + WRITE_SIZE" % kname,
                          "kernel": "%s (all launches of one frame)" % kname, "kernel_ms": broad_ms,
                          "frame_kernels_ms": frame_kernels_ms, "frame_kernels_serial_ms": serial_ms,
