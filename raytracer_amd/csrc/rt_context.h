@@ -31,6 +31,10 @@ struct rt_context {
     bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
     bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
     bool mf_binned = true;                        //   rounds after the camera rays': the binned scan (RT_MFMA_BINNED=0: plain)
+    // measured on the 4K room with 256 .. 2048 spheres (tools/lattice_probe.py): file order wins up to 256 solids, own order
+    // + group records per tile in round 0 from 512, the binned scan in the later rounds from about 1000 (28 groups)
+    int mf_min_bounded = 16 * BROAD_GROUP;        //   bounded solids from which the table takes its own order (RT_MFMA_MIN_BOUNDED)
+    int mf_binned_min_groups = 28;                //   groups from which the later rounds use the binned scan (RT_MFMA_BINNED_MIN)
     int mf_list_cap = MFB_LIST;                   //   places used in a group's ray list (RT_MFMA_LIST: tests of the all-rays path)
     unsigned* d_mf_perm = nullptr;                //   place in the table's order -> file index of the solid
     double* d_mf_cand = nullptr;                  //   place -> (point a, radius) of the solid, for the exact phase

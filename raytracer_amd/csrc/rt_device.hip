@@ -122,6 +122,8 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
+    if (const char* e = getenv("RT_MFMA_MIN_BOUNDED")) h->mf_min_bounded = atoi(e);
+    if (const char* e = getenv("RT_MFMA_BINNED_MIN")) h->mf_binned_min_groups = atoi(e);
     if (const char* e = getenv("RT_MFMA_LIST")) { const int v = atoi(e); if (v >= 0 && v <= MFB_LIST) h->mf_list_cap = v; }
     if (const char* e = getenv("RT_BROAD_MFMA")) h->broad_mfma = atoi(e) != 0;
     if (const char* e = getenv("RT_GRID_DENSITY")) { const double v = atof(e); if (v > 0.01 && v < 100.0) h->grid_density = v; }
@@ -444,12 +446,12 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     if (alw.empty()) alw.push_back(0.0);
 
     // the matrix-core scan's table; its group records can reach further out than any record, and cmax covers both
-    // Its own (Morton) record order and the group-record pass pay only where a whole round is camera rays -- one path per
-    // pixel -- and there are groups enough to drop; otherwise the table keeps the file order (consecutive solids of a
-    // scene file tend to be neighbours along some line, which packs a ray's hits into few mask words).
+    // Its own (Morton) record order lets the scan ask the groups' bounding spheres first (per tile for the camera rays,
+    // per ray afterwards); it needs groups enough to drop.  Below that the table keeps the file order (consecutive solids
+    // of a scene file tend to be neighbours along some line, which packs a ray's hits into few mask words).
     int n_bounded = 0;
     for (int i = 0; i < n_prims; i++) if (!always[i] && br[i] >= 0) n_bounded++;
-    const bool mf_reorder = h->mf_cull && spp == 1 && n_bounded >= 8 * BROAD_GROUP;
+    const bool mf_reorder = h->mf_cull && n_bounded >= h->mf_min_bounded;
     const MfTable mt = mf_build_table(rec.data(), n_prims, cmax, mf_reorder);
     if (mt.reordered && mt.cmax > cmax) cmax = mt.cmax;
 
@@ -644,11 +646,12 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     constexpr int MFB_BLOCK = 1024, MFB_RAYS = MFB_BLOCK / 2;
     const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)MFB_RAYS * 64 + (size_t)MFB_GROUPS * MFB_LIST * 2 +
                               (size_t)MFB_RAYS * 4 + 2 * MFB_GROUPS * 4;
+    const bool use_binned = h->mf_reordered && h->mf_binned && h->n_groups >= h->mf_binned_min_groups;
     unsigned mgrid = 1, mgrid_cull = 1;
     if (use_mfma) {
         e = mfma_grid<MF_BLOCK, false>(h, mfma_lds, &mgrid);
         if (e == hipSuccess && h->mf_reordered) e = mfma_grid<MF_BLOCK, true>(h, mfma_lds, &mgrid_cull);
-        if (e == hipSuccess && h->mf_reordered && h->mf_binned)
+        if (e == hipSuccess && use_binned)
             e = hipFuncSetAttribute((const void*)broad_mfma_binned_kernel<MFB_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)binned_lds);
         if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad_mfma_kernel setup: ") + hipGetErrorString(e));
         for (int p = 0; p < nsub; p++) { wp[p].kp.wide = 1; wp[p].kp.mf_perm = h->d_mf_perm; wp[p].kp.mf_cand = h->d_mf_cand; }
@@ -710,7 +713,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     // the camera rays' round of a table in its own order asks the group records first
                     if (it == 0 && h->mf_reordered)
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
-                    else if (h->mf_reordered && h->mf_binned)
+                    else if (use_binned)
                         hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale, h->mf_list_cap);
                     else
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);

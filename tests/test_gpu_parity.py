@@ -238,9 +238,10 @@ def test_binned_scan_variants_do_not_change_bits(renderer, monkeypatch, env):
     assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
 
 
-def test_reordered_table_with_unbounded_records_matches_oracle(renderer):
+def test_reordered_table_with_unbounded_records_matches_oracle(monkeypatch):
     """More planes than the always-tested table takes (64): the rest stay records of the scan that every ray keeps, here
-    in a table that is in its own (Morton) order -- 320 spheres, one path per pixel -- with the group-record pass on."""
+    in a table that is in its own (Morton) order -- forced for these 320 spheres, with the group records asked per tile in
+    the camera rays' round and the binned scan afterwards."""
     import random
     rng = random.Random(7)
     objs = synth._room(2, 7)
@@ -252,13 +253,17 @@ def test_reordered_table_with_unbounded_records_matches_oracle(renderer):
     header = {"num_threads": 4, "num_objs": len(objs), "exposure": 1, "num_blurs": 0, "paths_per_pixel": 1, "max_ray_depth": 3,
               "scale": 768 / 40.0, "width": 768, "height": 432, "lens_radius": 1.0, "focal_length": 60}
     sc = S.loads(S.dumps(header, objs))
-    renderer.set_option(api.OPT_OVERLAP, 1)           # one queue of 331 776 rays: more batches than workgroups, no slices
+    monkeypatch.setenv("RT_MFMA_MIN_BOUNDED", "64")
+    monkeypatch.setenv("RT_MFMA_BINNED_MIN", "1")
+    ren = api.Renderer(0)
     try:
-        g, _ = _compare(renderer, sc, "320 spheres + 78 planes")
-        t = renderer.timing()
+        ren.set_option(api.OPT_OVERLAP, 1)            # one queue of 331 776 rays: more batches than workgroups, no slices
+        g, _ = _compare(ren, sc, "320 spheres + 78 planes")
+        t = ren.timing()
     finally:
-        renderer.set_option(api.OPT_OVERLAP, 2)
-    assert t["broad_tiles"] > 0 and t["broad_records"] % 32 == 0 and t["broad_records"] >= 320 + 14
+        ren.close()
+    # own order: the always-tested solids are not in the table (file order would give 416 records)
+    assert t["broad_records"] == 352 and 0 < t["broad_tiles"] < g["rays"] // 32 * 11
 
 
 def test_moved_camera_matches_oracle(renderer, golden_dir):
