@@ -1,4 +1,4 @@
-// Pipeline, part 1b: the broad phase on the matrix cores (broad_mfma_kernel).
+// Pipeline, part 1b: the broad phase on the matrix cores (broad_mfma_kernel, broad_mfma_binned_kernel).
 // A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
 //
 // broad_kernel spends 6 of its 9 vector instructions per (ray, record) pair on two dot products, hb = a.c + od and
@@ -13,7 +13,8 @@
 // Range: f16 ends at 65504 and has a fixed absolute resolution of 2^-24 below 2^-14 (subnormals, which the conversions
 // and the MFMA keep: measured).  All lengths are therefore scaled by a power of two s (exact in float) chosen from the
 // scene so that the largest record coordinate lands near 64: squares stay below 2^12, low pieces stay far above 2^-24.
-// A ray whose scaled constants leave the range (origin further than about four scene radii from the scene's centre) is
+// broad_setup hands the ray over with its origin moved to the point of its line nearest the scene's centre (at most two
+// scene radii out), so the scaled constants of a finite ray stay in range; a ray whose constants leave it all the same is
 // not "ordinary": its list is marked as overflowed and the exact test sees every solid.
 //
 // Error bounds (u = 2^-24, S = |o| + cmax as in broad_setup): hb drops at most 2^-20 |a||c| + 2^-21 |od| <= 24 u S and
@@ -29,7 +30,6 @@
 // Output tile: column = ray (lane & 31), row = (reg & 3) + 8 (reg >> 2) + 4 h.  Record 16 h' + reg of a group sits in the
 // row that lane half h' reads in register reg, so a lane's 16 sign bits are the keep bits of 16 consecutive records.
 #pragma once
-
 
 namespace {
 
