@@ -425,23 +425,23 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 gm = own ? full : 0u;
             }
             // group k's rays of this wave as a ballot word, kept by lane k; one LDS atomic (all 32 groups at once)
-            // reserves the wave's places in the groups' lists; then every ray enters itself for each of its bits
+            // reserves the wave's places in the groups' lists
             unsigned bw = 0;                                   // lane k < 32: bit r set iff ray r of the wave keeps group k
 #pragma unroll
             for (int k = 0; k < 32; k++) {
                 const unsigned b = (unsigned)__ballot((gm & (0x80000000u >> k)) != 0u);     // (upper lane half: gm = 0)
                 if (lane == k) bw = b;
             }
-            unsigned base = 0;
-            if (lane < 32 && bw != 0u) base = atomicAdd(&gcount[lane], (unsigned)__popc(bw));
-            unsigned mine_bits = gm;
-            while (__ballot(mine_bits != 0u)) {                // whole waves: a lane another lane reads from must be running
-                const bool go = mine_bits != 0u;
-                const int k = go ? __builtin_clz(mine_bits) : 0;
-                mine_bits &= ~(0x80000000u >> k);              // (clears bit 31 of a zero word: still zero)
-                const unsigned bk = (unsigned)__shfl((int)bw, k, 64), basek = (unsigned)__shfl((int)base, k, 64);
-                const unsigned place = basek + (unsigned)__popc(bk & ((1u << r) - 1u));
-                if (go && place < (unsigned)list_cap) lists[k * MFB_LIST + place] = (unsigned short)local;
+            // lane k enters group k's rays of this wave in the group's list (places past the list's end stay unwritten:
+            // the group is then scanned for all rays of the pass)
+            if (lane < 32 && bw != 0u) {
+                unsigned place = atomicAdd(&gcount[lane], (unsigned)__popc(bw));
+                unsigned short* const lk = lists + lane * MFB_LIST;
+                while (bw != 0u && place < (unsigned)list_cap) {
+                    const int rr = __builtin_ctz(bw);
+                    bw &= bw - 1u;
+                    lk[place++] = (unsigned short)(wv * 32 + rr);
+                }
             }
             __syncthreads();                                   // the lists are complete
             // ---- items (group, 32 rays): lane g < 32 holds group g's range of item numbers.  A group whose list did
