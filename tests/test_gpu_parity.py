@@ -266,6 +266,24 @@ def test_reordered_table_with_unbounded_records_matches_oracle(monkeypatch):
     assert t["broad_records"] == 352 and 0 < t["broad_tiles"] < g["rays"] // 32 * 11
 
 
+def test_flat_sphere_layer_in_own_table_order_matches_oracle(renderer):
+    """600 spheres in one plane z = const (no extent along one axis for the Morton curve), some of them concentric:
+    enough for the scan's table to take its own order; pinned by the oracle."""
+    objs = synth._room(2, 0)
+    for i in range(600):
+        x, y = -18.0 + 1.5 * (i % 25), -18.0 + 1.5 * (i // 25)
+        if i % 50 == 49:
+            x, y = -18.0, -18.0                       # a pile of concentric spheres: ties go to the lower file index
+        objs.append({"shape": "sphere", "is_light": False, "center": [x, y, -20.0], "radius": 0.4 + 0.001 * (i % 7),
+                     "diffuse": [0.5, 0.4, 0.3], "specular": [0.2, 0.2, 0.2], "specular_exp": 20, "refraction_index": 0,
+                     "refraction_diffuse": [0, 0, 0], "refraction_specular": [0, 0, 0], "refraction_specular_exp": 0})
+    header = {"num_threads": 4, "num_objs": len(objs), "exposure": 1, "num_blurs": 0, "paths_per_pixel": 1, "max_ray_depth": 3,
+              "scale": 320 / 40.0, "width": 320, "height": 180, "lens_radius": 0.5, "focal_length": 60}
+    sc = S.loads(S.dumps(header, objs))
+    _compare(renderer, sc, "flat layer of 600 spheres")
+    assert renderer.timing()["broad_records"] == 608          # 600 spheres in 19 groups, the room's solids not among them
+
+
 def test_moved_camera_matches_oracle(renderer, golden_dir):
     """Header extension "camera": the device and the oracle read the same three parameters (the reference's constant
     (0,0,40) is their default); no reference output exists for a moved camera, so this case is pinned by the oracle only."""
