@@ -64,10 +64,20 @@ struct Plane : Solid {
 };
 
 struct Face : Plane {             // point = verts[0]
-    std::vector<Point> verts;
+    std::vector<Point> verts;     // (the reference holds a Point*: verts[i] reads the same)
     int num = 0;
     Material material;
-    Face(const Vector& n, const std::vector<Point>& v) : Plane(v.empty() ? Point() : v[0], n), verts(v), num((int)v.size()) {}
+    // As Face::Face (src/geometry.cpp:152-159): the normal is stored as given, NOT normalised here -- the loader has
+    // normalised it once already (src/readShape.cpp:95), and a second pass could move a component by an ulp.
+    // The vertices are copied; the caller keeps ownership of `v`.
+    Face(const Vector& n, int num_verts, Point* v) : verts(v, v + (num_verts > 0 ? num_verts : 0)), num(num_verts > 0 ? num_verts : 0) {
+        point = num ? verts[0] : Point();
+        norm = n;
+    }
+    Face(const Vector& n, const std::vector<Point>& v) : verts(v), num((int)v.size()) {
+        point = num ? verts[0] : Point();
+        norm = n;
+    }
 };
 
 // What the reference's loader leaves in globals (src/readShape.cpp:13-24, src/main.cpp:16-32), under the same names.

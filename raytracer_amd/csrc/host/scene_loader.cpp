@@ -211,7 +211,12 @@ std::vector<Solid*>* parse_scene_text(const std::string& text) {
                 }
             } else if (shape.str == "plane") {                              // readShape.cpp:68-90
                 vec3(o, "point", a); vec3(o, "normal", n);
-                Plane* pl = new Plane(Point(a[0], a[1], a[2]), Vector(n[0], n[1], n[2]));
+                // a plane's normal is normalised twice: by the loader (readShape.cpp:73) and again by Plane::Plane
+                // (geometry.cpp:97).  The second pass is not always the identity: where the first result's squared
+                // length rounds to 1 - 2^-53 it moves components by an ulp.  (A face's normal is normalised once, :95.)
+                Vector nv(n[0], n[1], n[2]);
+                nv.normalize();
+                Plane* pl = new Plane(Point(a[0], a[1], a[2]), nv);
                 objs->push_back(pl);
                 pl->is_light = false;   // Solid::is_light is never written for an emitting plane (readShape.cpp:75)
                 if (light) {
@@ -236,7 +241,9 @@ std::vector<Solid*>* parse_scene_text(const std::string& text) {
                     for (int k = 0; k < 3; k++) if (v->arr[k]->kind != JVal::NUM) throw SceneError("a vertex must hold numbers");
                     pts.push_back(Point(v->arr[0]->num, v->arr[1]->num, v->arr[2]->num));
                 }
-                Face* f = new Face(Vector(n[0], n[1], n[2]), pts);
+                Vector nv(n[0], n[1], n[2]);
+                nv.normalize();                                             // readShape.cpp:95; Face::Face keeps it as given
+                Face* f = new Face(nv, (int)pts.size(), pts.data());
                 objs->push_back(f);
                 f->is_light = light;
                 if (light) {

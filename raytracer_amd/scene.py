@@ -175,7 +175,9 @@ def from_objects(header: dict, objects: list, frame_seed: int = 0) -> Scene:
         elif shape == "plane":                                  # readShape.cpp:68-90
             p[PR_KIND] = KIND_PLANE
             p[PR_A:PR_A + 3] = _vec3(obj, "point")
-            p[PR_N:PR_N + 3] = _normalize(_vec3(obj, "normal"))
+            # normalised twice, by the loader (readShape.cpp:73) and by Plane::Plane (geometry.cpp:97); the second pass can
+            # move a component by an ulp.  A face's normal (below) is normalised once (readShape.cpp:95).
+            p[PR_N:PR_N + 3] = _normalize(_normalize(_vec3(obj, "normal")))
             # Solid::is_light is never written for an emitting plane (readShape.cpp:75): treated as false
             p[PR_LIGHT] = 0.0
             if light:

@@ -82,6 +82,15 @@ def _scenes():
     tilted_normal = _face([(5, -12, -29), (12, -12, -29), (12, 2, -29), (5, 2, -29)], (0.1, 0, 1))          # normal off the axis
     yield "box_walls_and_non_box_walls", _header(9, width=64, height=36), [FLOOR, CEIL_LIGHT, back_cw, left, right_neg, strip,
                                                                             tilted_normal, _sphere((0, -7, -12), 5), _sphere((-9, -8, -6), 3, glass=1.5)]
+    # A tilted plane whose normal changes under a second normalisation: the reference normalises a plane's normal in its
+    # loader and again in Plane::Plane (readShape.cpp:73, geometry.cpp:97); for (1, 20, -1) the second pass moves every
+    # component by an ulp.  The tilted face beside it carries the same normal, which is normalised once (readShape.cpp:95).
+    # (Lit from close by so that paths off the plane reach an emitter: with the once-normalised normal a dozen radiance
+    # doubles of this frame differ from the reference's.)
+    tilted_floor = _plane((0, -8, 0), (1, 20, -1))
+    tilted_face = _face([(-9, -3, -16), (9, -2.1, -16), (9.4, 5.9, -16), (-8.6, 5, -16)], (1, 20, -1))
+    yield "tilted_plane_normal_normalised_twice", _header(5, width=64, height=36), [tilted_floor, CEIL_LIGHT, _sphere((0, 16, -10), 9, light=True),
+                                                                                     tilted_face, _sphere((2, -3, -9), 4)]
     many = [FLOOR, CEIL_LIGHT] + [_sphere((-18 + 1.2 * (i % 31), -10 + 1.2 * (i // 31), -12 - 0.1 * i), 0.5) for i in range(90)]
     yield "row_of_spheres_overflowing_lists", _header(len(many), width=64, height=36, depth=2, lens=0.0), many
 

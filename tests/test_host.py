@@ -74,6 +74,34 @@ def test_camera_header_key_is_optional_and_read_by_both_loaders(golden_dir, tmp_
     assert np.array_equal(params.view(np.uint64), sc.params().view(np.uint64))
 
 
+def test_plane_normal_is_normalised_twice_and_face_normal_once(tmp_path):
+    """readShape.cpp:73 + geometry.cpp:97 normalise a plane's normal twice, readShape.cpp:95 a face's once.  For
+    (1, 20, -1) the second pass moves every component by an ulp, so the two solids' normals differ; both loaders
+    must reproduce exactly that."""
+    import math
+    from edge_scenes import SCENES, text_of
+
+    def nrm(n):                       # Vector::normalize: sqrt of the left-to-right sum of squares, one division each
+        t = 0.0
+        for c in n:
+            t += c * c
+        return [c / math.sqrt(t) for c in n]
+
+    once = nrm([1.0, 20.0, -1.0])
+    twice = nrm(once)
+    assert once != twice
+    _, header, objs = [s for s in SCENES if s[0] == "tilted_plane_normal_normalised_twice"][0]
+    text = text_of(header, objs)
+    sc = S.loads(text)
+    assert sc.prims[0, S.PR_KIND] == S.KIND_PLANE and sc.prims[3, S.PR_KIND] == S.KIND_FACE
+    assert sc.prims[0, S.PR_N:S.PR_N + 3].tolist() == twice
+    assert sc.prims[3, S.PR_N:S.PR_N + 3].tolist() == once
+    dst = str(tmp_path / "tilted.json")
+    open(dst, "w").write(text)
+    prims = _dump_tables(dst)[1]
+    assert np.array_equal(prims.view(np.uint64), sc.prims.ravel().view(np.uint64))
+
+
 def test_scene_errors():
     with pytest.raises(S.SceneError):
         S.loads("")
