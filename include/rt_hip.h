@@ -196,8 +196,10 @@ int rt_expose_device(rt_handle h, const double* d_rgb, int width, int height, do
  * a fixed array inside the library (12 MiB + 16 KiB on every GPU the library is loaded on, held until the process ends)
  * instead of buffers allocated on first use; the call makes no hipMalloc / hipFree.  Frames of more than
  * RT_NOALLOC_MAX_PIXELS pixels are refused with RT_ERR_ARG (rt_last_error says so).  Every handle on a GPU shares that
- * GPU's array: two calls that overlap in time on one GPU (different streams or threads) race; calls on one stream, or
- * ordered by events, do not.  rt_create prepares the array for its device. */
+ * GPU's array.  Calls with blur passes therefore run one after the other on a GPU: each makes its stream wait for an event
+ * the previous one recorded (whatever its stream, handle or thread).  Under graph capture that wait is not possible and is
+ * left out: graphs that use this call must not run at the same time on one GPU, or they race on the array.
+ * rt_create prepares the array for its device (if that fails, only this call is affected: it returns RT_ERR_HIP). */
 #define RT_NOALLOC_MAX_PIXELS 262144      /* 512 x 512; the reference's own scene.json is 400 x 400 */
 int rt_expose_device_noalloc(rt_handle h, const double* d_rgb, int width, int height, double exposure, int num_blurs,
                              int32_t* d_img, void* stream);
@@ -235,18 +237,6 @@ int rt_last_timing(rt_handle h, rt_timing* out);
 /* Text of the last error on this context (never NULL). */
 const char* rt_last_error(rt_handle h);
 
-/* Kernel self-tests used by the parity suite: evaluate the device math on n inputs.
- * fn: 0 sin, 1 cos, 2 acos, 3 pow(x,y), 4 x/y, 5 sqrt(x), 6 next RNG state (state passed
- * in the low 32 bits of x's bit pattern).  x, y, out are HOST double arrays. */
-int rt_selftest_math(rt_handle h, int fn, int n, const double* x, const double* y, double* out);
-
-/* Broad-phase self-test: for n independent (ray, bounding sphere) pairs evaluate the FP32
- * conservative test exactly as the render kernel does.  flags[i]: 0 = dropped, 1 = kept for
- * the exact test, 2 = dropped as wholly behind the origin.  Host arrays: origins, dirs,
- * centres are double[n*3], radii double[n]. */
-int rt_selftest_broad(rt_handle h, int n, const double* origins, const double* dirs, const double* centres,
-                      const double* radii, int32_t* flags);
-
 /* ---- one process, several GPUs ------------------------------------------------------------------------------------------
  * The reference renders one frame on num_threads threads that share the Color array, thread t taking rows t, t+T, ...
  * (main.cpp:250,303-313), then exposes and writes it (:314,327).  rt_multi_* is that for the GPUs of one node: rank r =
@@ -274,40 +264,25 @@ int rt_multi_upload_scene(rt_multi_handle m, const double* params, int n_prims, 
  *   tile_rows : rows per tile of the cyclic partition; 0 = default (8, or one band per rank when there are blur passes)
  *   img       : int32[height*width], what writeImage takes (pngUtil.c:4);  rays: out, ray segments traced on all ranks */
 int rt_multi_render_image(rt_multi_handle m, int tile_rows, int32_t* img, uint64_t* rays);
-/* Wall-clock milliseconds of the last rt_multi_render_image (enqueue to frame on the host). */
+/* The same frame in two calls, so that frames overlap: rt_multi_render_begin enqueues everything on every rank (the ranks
+ * beyond the first through persistent worker threads) and returns without waiting; rt_multi_render_end waits for the
+ * OLDEST frame begun, copies it out and returns its ray count.  At most two frames may be in flight: the gather, the
+ * re-ordering and the copy to the host of frame i run on streams of their own while the ranks render frame i + 1.
+ * Replaces main.cpp:304-315 like rt_multi_render_image, which is begin followed by end. */
+int rt_multi_render_begin(rt_multi_handle m, int tile_rows);
+int rt_multi_render_end(rt_multi_handle m, int32_t* img, uint64_t* rays);
+/* Wall-clock milliseconds of the last frame ended (from the start of its begin call to the frame on the host), and the
+ * two host-side parts of it: the time the begin call took to enqueue the frame and the time the end call waited. */
 double rt_multi_last_ms(rt_multi_handle m);
+int rt_multi_last_times(rt_multi_handle m, double* enqueue_ms, double* wait_ms);
+/* 1 when the context exchanges rows through RCCL (more than one GPU; or one rank with RT_MULTI_FORCE_RCCL=1 in the
+ * environment, which makes that rank send its rows and over-exposure bits to itself through the same RCCL calls), else 0. */
+int rt_multi_uses_rccl(rt_multi_handle m);
+/* Text of the last error on this context; with a NULL handle: why the last rt_multi_create failed. */
 const char* rt_multi_last_error(rt_multi_handle m);
 /* Host arithmetic of the gather: the row of the gathered buffer [n_gpus][pad_rows][width] that holds frame row y
  * (pad_rows >= the largest row count of a rank).  No GPU call. */
 int rt_gather_source_row(int height, int tile_rows, int world, int pad_rows, int y);
-
-/* Host-only self-test (no GPU call): the bounding sphere the library gives a face before the FP32 broad phase and the
- * grid may cull it.  Face::intersect (geometry.cpp:160-168) accepts, per vertex, a half-plane bordered by the line through
- * v_i perpendicular to edge i -- the polygon only for rectangles, a larger or unbounded region otherwise -- and the sphere
- * must hold that whole region.  normal: the unit normal as the loader leaves it (readShape.cpp:95).
- * Returns 1 and (centre[3], radius) when the region is bounded, 0 when the face is tested for every ray, < 0 on error. */
-int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius);
-
-/* Host-only self-test (no GPU call): how broad_mfma_kernel's record table represents one broad-phase record
- * (cx, cy, cz, w = R^2 - |c|^2) of a scene whose largest record extent is cmax.  scale: the power of two by which lengths
- * are multiplied; pieces[8]: the two f16 pieces (as doubles) of s cx, s cy, s cz and s^2 w.  The pieces of a coordinate
- * sum to it within 2^-21 of its magnitude, those of w to at least s^2 w (w is rounded towards "keep"); an infinite w
- * (never / always kept record) becomes -/+ 65504. */
-int rt_mfma_record_pieces(const double* record, double cmax, double* scale, double* pieces);
-
-/* Host-only self-test (no GPU call): the record order of broad_mfma_kernel's table for n bounding spheres (T = 0) and the
- * bounding spheres of its groups of 32.  radii[i] = -1: a solid that is never kept (left out of a reordered table), any
- * other negative radius: an unbounded solid.  reorder = 0: file order.  perm[k] (k < 32 * groups): the index of the solid at
- * place k, 0x7fffffff where a place holds none.  group_spheres[4 g ..]: centre and radius of group g's sphere (radius -1:
- * empty group, +inf: the group holds an unbounded solid).  Returns the number of groups, < 0 on error (too small buffers). */
-int rt_mfma_table_order(int n, const double* centres, const double* radii, int reorder, uint32_t* perm, int perm_cap,
-                        double* group_spheres, int group_cap);
-
-/* Self-test of the broad phase on the matrix cores: every one of n_rays rays against every one of n_rec bounding spheres,
- * evaluated exactly as broad_mfma_kernel does.  masks: uint32[n_rays * ceil(n_rec / 32)] (HOST); bit 31 - k of
- * masks[ray * groups + g] is set iff record 32 g + k is kept for the ray. */
-int rt_selftest_broad_mfma(rt_handle h, int n_rays, const double* origins, const double* dirs, int n_rec, const double* centres,
-                           const double* radii, uint32_t* masks);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,8 @@ EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_ro
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
            "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces", "rt_mfma_table_order",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
-           "rt_multi_render_image", "rt_multi_last_ms", "rt_multi_last_error", "rt_gather_source_row")
+           "rt_multi_render_image", "rt_multi_render_begin", "rt_multi_render_end", "rt_multi_last_ms", "rt_multi_last_times",
+           "rt_multi_uses_rccl", "rt_multi_last_error", "rt_gather_source_row")
 
 
 class RtError(RuntimeError):
@@ -113,6 +114,14 @@ def load_library(path: str = LIB_PATH):
     l.rt_multi_upload_scene.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
     l.rt_multi_render_image.restype = C.c_int
     l.rt_multi_render_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    l.rt_multi_render_begin.restype = C.c_int
+    l.rt_multi_render_begin.argtypes = [C.c_void_p, C.c_int]
+    l.rt_multi_render_end.restype = C.c_int
+    l.rt_multi_render_end.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    l.rt_multi_last_times.restype = C.c_int
+    l.rt_multi_last_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    l.rt_multi_uses_rccl.restype = C.c_int
+    l.rt_multi_uses_rccl.argtypes = [C.c_void_p]
     l.rt_multi_last_ms.restype = C.c_double
     l.rt_multi_last_ms.argtypes = [C.c_void_p]
     l.rt_multi_last_error.restype = C.c_char_p
@@ -318,7 +327,7 @@ class MultiRenderer:
         self.h = C.c_void_p()
         rc = self.lib.rt_multi_create(C.byref(self.h), int(n_gpus))
         if rc != RT_OK:
-            raise RtError(rc, f"rt_multi_create({n_gpus}) failed")
+            raise RtError(rc, f"rt_multi_create({n_gpus}) failed: " + self.lib.rt_multi_last_error(None).decode())
         self.scene = None
 
     def _check(self, rc):
@@ -358,6 +367,25 @@ class MultiRenderer:
         rays = C.c_uint64(0)
         self._check(self.lib.rt_multi_render_image(self.h, int(tile_rows), img.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(rays)))
         return dict(img=img, rays=int(rays.value), ms=float(self.lib.rt_multi_last_ms(self.h)))
+
+    def uses_rccl(self) -> bool:
+        return self.lib.rt_multi_uses_rccl(self.h) == 1
+
+    def begin(self, tile_rows: int = 0):
+        """Enqueue a frame on every rank without waiting (at most two frames in flight)."""
+        if self.scene is None:
+            raise RtError(-3, "no scene uploaded")
+        self._check(self.lib.rt_multi_render_begin(self.h, int(tile_rows)))
+
+    def end(self):
+        """Wait for the oldest frame begun: dict(img, rays, ms, enqueue_ms, wait_ms)."""
+        sc = self.scene
+        img = np.zeros((sc.height, sc.width), dtype=np.int32)
+        rays = C.c_uint64(0)
+        self._check(self.lib.rt_multi_render_end(self.h, img.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(rays)))
+        enq, wait = C.c_double(0), C.c_double(0)
+        self.lib.rt_multi_last_times(self.h, C.byref(enq), C.byref(wait))
+        return dict(img=img, rays=int(rays.value), ms=float(self.lib.rt_multi_last_ms(self.h)), enqueue_ms=enq.value, wait_ms=wait.value)
 
 
 # ------------------------------------------------------------------ host post-process

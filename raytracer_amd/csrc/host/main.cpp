@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
         if (ref_order || host_expose) { fprintf(stderr, "rt_main: --gpus cannot be combined with --reference-order or --host-expose\n"); return 2; }
         rt_multi_handle m = nullptr;
         int rc = rt_multi_create(&m, gpus);
-        if (rc != RT_OK) { fprintf(stderr, "rt_main: rt_multi_create(%d) failed (%d): not that many GPUs, or RCCL not loadable\n", gpus, rc); return 1; }
+        if (rc != RT_OK) { fprintf(stderr, "rt_main: rt_multi_create(%d) failed (%d): %s\n", gpus, rc, rt_multi_last_error(nullptr)); return 1; }
         rc = rt_multi_upload_scene(m, sc.params.data(), sc.n_prims(), sc.prims.data(), sc.n_mats(), sc.mats.data(), sc.n_verts(), sc.verts.data());
         if (rc != RT_OK) { fprintf(stderr, "rt_main: %s\n", rt_multi_last_error(m)); rt_multi_destroy(m); return 1; }
         std::vector<int> img((size_t)W * H);

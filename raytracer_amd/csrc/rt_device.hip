@@ -1,4 +1,4 @@
-// librt_hip.so -- render kernels for gfx950 (MI355X) and their C ABI (include/rt_hip.h).
+// librt_hip.so -- render kernels for gfx950 (MI355X) and their C ABI (include/rt_hip.h; self-tests: include/rt_hip_selftest.h).
 //
 // What is computed: the per-pixel render loop of samkottler/rayTracer,
 // /root/reference/src/main.cpp:247-289 (do_rays_i) with everything it calls:
@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "../../include/rt_hip_selftest.h"
 #include "rt_math.h"
 
 // The translation unit, in dependency order:
@@ -64,28 +65,36 @@
 // library's code object is loaded there.  Layout: [0, NOALLOC_TAPS_BYTES) the 41 x 41 taps (written once per device by
 // noalloc_setup), then two buffers of RT_NOALLOC_MAX_PIXELS * 3 doubles.  In host code the array's name is only a
 // handle for hipGetSymbolAddress: the address each device holds it at is looked up once per device and kept in
-// g_scratch_ptr, and only that pointer is ever passed to kernels or copies.
+// g_noalloc[device].ptr, and only that pointer is ever passed to kernels or copies.
 constexpr size_t NOALLOC_TAPS_BYTES = 16384;                                        // 1681 doubles, padded
 constexpr size_t NOALLOC_BUF_BYTES = (size_t)RT_NOALLOC_MAX_PIXELS * 3 * sizeof(double);
 constexpr size_t NOALLOC_BYTES = NOALLOC_TAPS_BYTES + 2 * NOALLOC_BUF_BYTES;
 static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 
 constexpr int NOALLOC_MAX_DEVICES = 64;
-static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES];     // per device: where that device holds `scratch`; null = not set up
-static std::mutex g_scratch_mutex;
+// per device: where that device holds `scratch` (null = not set up) and an event recorded after the last call's launches.
+// Every handle and stream on a GPU shares the GPU's array, so a call first makes its stream wait for that event: calls
+// that would overlap on one GPU run one after the other instead of racing.  (A stream under graph capture cannot wait for
+// an event recorded outside the capture; there the ordering is left to the graph and its caller.)
+struct NoallocDevice { unsigned char* ptr = nullptr; hipEvent_t last_use = nullptr; };
+static NoallocDevice g_noalloc[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;     // guards g_noalloc and keeps a call's wait / launches / record together
 
-// once per device, with that device current (rt_create): look up the device's copy of the array and fill in the taps
+// once per device, with that device current (rt_create): look up the device's copy of the array and fill in the taps.
+// A failure here is not fatal to the context: rt_expose_device_noalloc then refuses, everything else works.
 static int noalloc_setup(rt_context* h) {
     if (h->device < 0 || h->device >= NOALLOC_MAX_DEVICES) return RT_OK;            // rt_expose_device_noalloc will refuse
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (g_scratch_ptr[h->device]) return RT_OK;
+    NoallocDevice& nd = g_noalloc[h->device];
+    if (nd.ptr) return RT_OK;
     unsigned char* ptr = nullptr;
     HIP_TRY(h, hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return fail(h, RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
     const std::vector<double> k = bloom_taps();
     static_assert(BLOOM_K * BLOOM_K * sizeof(double) <= NOALLOC_TAPS_BYTES, "taps do not fit their part of the array");
     HIP_TRY(h, hipMemcpy(ptr, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
-    g_scratch_ptr[h->device] = ptr;
+    if (!nd.last_use) HIP_TRY(h, hipEventCreateWithFlags(&nd.last_use, hipEventDisableTiming));
+    nd.ptr = ptr;
     return RT_OK;
 }
 
@@ -104,13 +113,14 @@ int rt_create(rt_handle* out, int device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
     h->cu_count = prop.multiProcessorCount;
     if (hipMalloc((void**)&h->d_ctrl, 256) != hipSuccess) { delete h; return RT_ERR_HIP; }
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || noalloc_setup(h) != RT_OK) {
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         hipFree(h->d_ctrl);
         delete h;
         return RT_ERR_HIP;
     }
+    if (noalloc_setup(h) != RT_OK) h->err.clear();   // only rt_expose_device_noalloc needs it, and it says so when called
     // tuning knobs for experiments; rt_set_option is the API for the same values
     if (const char* e = getenv("RT_MODE")) rt_set_option(h, RT_OPT_MODE, strcmp(e, "mega") == 0 ? RT_MODE_SINGLE_KERNEL : RT_MODE_PIPELINE);
     if (const char* e = getenv("RT_BLOCK")) rt_set_option(h, RT_OPT_BLOCK, atoi(e));
@@ -368,6 +378,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
         rec.insert(rec.end(), r4, r4 + 4);
         chunks.back().count++;
     }
+    const std::vector<float> rec_file = rec;       // one record per solid in file order, before any padding (mf_build_table indexes it by file index)
     // pad every LDS window to whole mask words inside the record stream
     {
         std::vector<float> padded;
@@ -452,7 +463,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     int n_bounded = 0;
     for (int i = 0; i < n_prims; i++) if (!always[i] && br[i] >= 0) n_bounded++;
     const bool mf_reorder = h->mf_cull && n_bounded >= h->mf_min_bounded;
-    const MfTable mt = mf_build_table(rec.data(), n_prims, cmax, mf_reorder);
+    const MfTable mt = mf_build_table(rec_file.data(), n_prims, cmax, mf_reorder);
     if (mt.reordered && mt.cmax > cmax) cmax = mt.cmax;
 
     GridHost gh;
@@ -772,6 +783,19 @@ int rt_render_streams_device(rt_handle h, double* d_rgb, int32_t* d_hit_ids, voi
     return render_common(h, 1, 1, 0, 1, d_rgb, d_hit_ids, stream);
 }
 
+}  // extern "C"
+
+// what the guard word of a finished render says; ctrl: the first 8 words of the context's control block
+static int guard_status(rt_handle h, const unsigned* ctrl) {
+    if (ctrl[1] & ERR_REJECT_GUARD)
+        return fail(h, RT_ERR_GUARD, "render: the glossy rejection loop did not accept within its guard at local pixel " + std::to_string(ctrl[7] - 1u) +
+                                     " (a glossy surface hit from behind: the reference never terminates on this scene)");
+    if (ctrl[1] & ERR_STACK) return fail(h, RT_ERR_GUARD, "render: bounce stack overflow (path longer than 2*max_ray_depth+2 vertices: no emitter in the scene?)");
+    return RT_OK;
+}
+
+extern "C" {
+
 int rt_finish(rt_handle h, uint64_t* rays) {
     if (!h) return RT_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -814,11 +838,7 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     h->timing.face_tests = r * h->n_faces;
     h->timing.face_vert_tests = r * h->n_face_verts;
     if (rays) *rays = r;
-    if (ctrl[1] & ERR_REJECT_GUARD)
-        return fail(h, RT_ERR_GUARD, "render: the glossy rejection loop did not accept within its guard at local pixel " + std::to_string(ctrl[7] - 1u) +
-                                     " (a glossy surface hit from behind: the reference never terminates on this scene)");
-    if (ctrl[1] & ERR_STACK) return fail(h, RT_ERR_GUARD, "render: bounce stack overflow (path longer than 2*max_ray_depth+2 vertices: no emitter in the scene?)");
-    return RT_OK;
+    return guard_status(h, ctrl);
 }
 
 int rt_stream_rays(rt_handle h, uint64_t* out, int n) {
@@ -912,10 +932,18 @@ int rt_expose_device_noalloc(rt_handle h, const double* d_rgb, int width, int he
     if (n > (size_t)RT_NOALLOC_MAX_PIXELS)
         return fail(h, RT_ERR_ARG, "rt_expose_device_noalloc: frame of " + std::to_string(n) + " pixels exceeds RT_NOALLOC_MAX_PIXELS (" +
                                    std::to_string(RT_NOALLOC_MAX_PIXELS) + "); use rt_expose_device");
-    unsigned char* const base = (h->device >= 0 && h->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[h->device] : nullptr;
+    if (h->device < 0 || h->device >= NOALLOC_MAX_DEVICES) return fail(h, RT_ERR_HIP, "rt_expose_device_noalloc: device index beyond the library's table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    const NoallocDevice& nd = g_noalloc[h->device];
+    unsigned char* const base = nd.ptr;
     if (!base) return fail(h, RT_ERR_HIP, "rt_expose_device_noalloc: the static buffer of this device was not set up by rt_create");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    // wait for the previous call's use of the array (any stream, any handle on this GPU); not under graph capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool ordered = cap == hipStreamCaptureStatusNone && nd.last_use != nullptr;
+    if (ordered && num_blurs > 0) HIP_TRY(h, hipStreamWaitEvent(st, nd.last_use, 0));
     const double* taps = (const double*)base;
     double* buf[2] = {(double*)(base + NOALLOC_TAPS_BYTES), (double*)(base + NOALLOC_TAPS_BYTES + NOALLOC_BUF_BYTES)};
     unsigned grid = (unsigned)((n + 255) / 256);
@@ -937,6 +965,7 @@ int rt_expose_device_noalloc(rt_handle h, const double* d_rgb, int width, int he
     }
     hipLaunchKernelGGL(expose_pack_kernel, dim3(grid), dim3(256), 0, st, d_rgb, (const double*)buf[cur], d_img, n, exposure);
     HIP_TRY(h, hipGetLastError());
+    if (ordered) HIP_TRY(h, hipEventRecord(nd.last_use, st));
     return RT_OK;
 }
 

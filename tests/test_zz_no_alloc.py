@@ -47,3 +47,22 @@ def test_noalloc_expose_largest_frame_and_limit(renderer):
         renderer.expose_device_noalloc(d.data_ptr(), 512, 513, 1.0, 1, o.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert e.value.code == -1 and "RT_NOALLOC_MAX_PIXELS" in str(e.value)
     assert api.NOALLOC_MAX_PIXELS == 512 * 512
+
+
+def test_noalloc_calls_on_two_streams_run_one_after_the_other(renderer):
+    """Every stream on the GPU shares the one buffer: the second call waits (by an event inside the library) for the
+    first, so two calls issued back to back on different streams both come out right."""
+    h, w, exposure, blurs = 200, 300, 1.0, 3
+    rgb_a, rgb_b = _frame(h, w, exposure, 11), _frame(h, w, exposure, 12)
+    want_a, _ = _both(renderer, rgb_a, exposure, blurs)[1], None
+    want_b = _both(renderer, rgb_b, exposure, blurs)[1]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d_a = torch.from_numpy(np.ascontiguousarray(rgb_a)).to("cuda:0")
+    d_b = torch.from_numpy(np.ascontiguousarray(rgb_b)).to("cuda:0")
+    o_a = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    o_b = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    renderer.expose_device_noalloc(d_a.data_ptr(), w, h, exposure, blurs, o_a.data_ptr(), s1.cuda_stream)
+    renderer.expose_device_noalloc(d_b.data_ptr(), w, h, exposure, blurs, o_b.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_a.cpu().numpy(), want_a) and np.array_equal(o_b.cpu().numpy(), want_b)
