@@ -102,12 +102,15 @@ typedef struct {
     uint64_t overflow_rays; /* pipeline: rays with a long candidate list (more than 6 mask words), tested against every solid by their whole wave */
     uint64_t broad_tiles;   /* matrix-core scan: (32 rays x 32 records) products executed, group records included */
     uint64_t broad_records; /* records of the matrix-core scan's table (a multiple of 32): what every other launch tests each ray against */
+    uint64_t accel_used;    /* last render: RT_ACCEL_SCAN or RT_ACCEL_WALK */
+    double shade_ms;        /* last render: sum over its shade_kernel launches (exact closest hit + one path segment   */
+                            /* per ray), measured like broad_ms only while RT_OPT_TIMING_DETAIL is on (else 0)          */
 } rt_timing;
 
 /* options for rt_set_option */
 enum {
     RT_OPT_MODE = 0,           /* RT_MODE_PIPELINE (default) or RT_MODE_SINGLE_KERNEL           */
-    RT_OPT_TIMING_DETAIL = 1,  /* 1: bracket every broad_kernel launch with HIP events          */
+    RT_OPT_TIMING_DETAIL = 1,  /* 1: bracket every scan and shade_kernel launch with HIP events */
     RT_OPT_BLOCK = 2,          /* workgroup size of the single-kernel renderer: 256/512/1024    */
     RT_OPT_BROAD_BLOCK = 3,    /* workgroup size of broad_kernel: 256/512/1024                  */
     RT_OPT_WG_PER_CU = 4,      /* persistent workgroups per CU, 0 = occupancy query             */
@@ -116,11 +119,17 @@ enum {
     RT_OPT_FUSE_NARROW = 7,    /* retired (the narrow phase always runs inside shade_kernel); accepted, ignored */
     RT_OPT_OVERLAP = 8,        /* 1..3 sub-pipelines, each with an equal share of the pixels and a stream of its  */
                                /* own, so that one's kernels fill the tails of the other's (default 2)            */
-    RT_OPT_ACCEL = 9           /* 0 (default): every ray is tested against every solid, the work get_intersection  */
-                               /* defines (main.cpp:34-43); 1: candidate solids come from a front-to-back walk of  */
-                               /* a uniform grid instead -- same closest hit, same output bits, far fewer tests    */
+    RT_OPT_ACCEL = 9           /* where a ray's candidate solids come from (RT_ACCEL_*); the closest hit and every   */
+                               /* output bit are the same whichever is used                                        */
 };
 enum { RT_MODE_PIPELINE = 0, RT_MODE_SINGLE_KERNEL = 1 };
+enum {
+    RT_ACCEL_SCAN = 0,         /* every ray is tested against every solid (through bounding spheres of groups of   */
+                               /* solids first), the work get_intersection defines (main.cpp:34-43)                */
+    RT_ACCEL_WALK = 1,         /* candidate solids come from a front-to-back walk of a uniform grid: far fewer tests */
+    RT_ACCEL_AUTO = 2          /* default: the library picks per scene by a measured threshold (the scan up to 1024  */
+                               /* bounded solids, the walk beyond); rt_timing.accel_used says which one ran         */
+};
 
 /* Create a context on HIP device `device` (index as HIP enumerates it).
  * Replaces: the allocation block of main(), main.cpp:300-303. */

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB", os.path.join(HERE, "librt_hip.so"))   # 
 RT_OK = 0
 # rt_set_option keys / values (include/rt_hip.h)
 OPT_MODE, OPT_TIMING_DETAIL, OPT_BLOCK, OPT_BROAD_BLOCK, OPT_WG_PER_CU, OPT_CHUNK_RECORDS, OPT_MAX_SLOTS, OPT_FUSE_NARROW, OPT_OVERLAP, OPT_ACCEL = range(10)
+ACCEL_SCAN, ACCEL_WALK, ACCEL_AUTO = 0, 1, 2
 MODE_PIPELINE, MODE_SINGLE_KERNEL = 0, 1
 NOALLOC_MAX_PIXELS = 262144         # RT_NOALLOC_MAX_PIXELS
 STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE", -4: "RT_ERR_SCENE",
@@ -44,7 +45,7 @@ class RtError(RuntimeError):
 class RtTiming(C.Structure):
     _fields_ = [("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("broad_ms", C.c_double), ("total_ms", C.c_double),
                 ("rays", C.c_uint64), ("candidates", C.c_uint64), ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
-                ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64), ("overflow_rays", C.c_uint64), ("broad_tiles", C.c_uint64), ("broad_records", C.c_uint64)]
+                ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64), ("overflow_rays", C.c_uint64), ("broad_tiles", C.c_uint64), ("broad_records", C.c_uint64), ("accel_used", C.c_uint64), ("shade_ms", C.c_double)]
 
 
 _lib = None

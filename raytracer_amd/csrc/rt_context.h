@@ -87,7 +87,12 @@ struct rt_context {
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
     int broad_mfma = 1;        // 1: the broad phase runs on the matrix cores (broad_mfma_kernel), 0: on the vector ALU (broad_kernel)
     bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
-    int accel = 0;             // pipeline: 1 = candidate lists from the grid walk instead of the scan of every record
+    int accel = RT_ACCEL_AUTO; // pipeline: candidate lists from the scan of every record (0), from the grid walk (1), or whichever is
+                               // faster for the scene (2: the walk above accel_min_bounded bounded solids)
+    int accel_min_bounded = MFB_GROUPS * BROAD_GROUP;   // RT_ACCEL_MIN_BOUNDED: the walk is chosen when the scene has more bounded solids
+                                                        // outside the always-tested table than this (1024: one window of the binned scan)
+    int n_bounded = 0;                   // such solids in the uploaded scene
+    int accel_used = RT_ACCEL_SCAN;      // what the last render used
     double grid_density = 1.0; // cells per listed solid the grid aims at (RT_GRID_DENSITY); 0.5 to 8 measured: flat optimum, 1 best on C4
 };
 

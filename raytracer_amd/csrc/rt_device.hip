@@ -129,6 +129,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_CHUNK_RECORDS")) rt_set_option(h, RT_OPT_CHUNK_RECORDS, atoi(e));
     if (const char* e = getenv("RT_OVERLAP")) rt_set_option(h, RT_OPT_OVERLAP, atoi(e));
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
+    if (const char* e = getenv("RT_ACCEL_MIN_BOUNDED")) h->accel_min_bounded = atoi(e);
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
@@ -166,7 +167,7 @@ int rt_set_option(rt_handle h, int key, int value) {
             if (value < 1 || value > RT_MAX_SUB) return fail(h, RT_ERR_ARG, "rt_set_option: overlap must be 1..3");
             h->overlap = value; return RT_OK;
         case RT_OPT_ACCEL:
-            if (value != 0 && value != 1) return fail(h, RT_ERR_ARG, "rt_set_option: accel must be 0 or 1");
+            if (value != RT_ACCEL_SCAN && value != RT_ACCEL_WALK && value != RT_ACCEL_AUTO) return fail(h, RT_ERR_ARG, "rt_set_option: accel must be 0 (scan), 1 (grid walk) or 2 (chosen per scene)");
             h->accel = value; return RT_OK;
         default: return fail(h, RT_ERR_ARG, "rt_set_option: unknown key");
     }
@@ -462,6 +463,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     // of a scene file tend to be neighbours along some line, which packs a ray's hits into few mask words).
     int n_bounded = 0;
     for (int i = 0; i < n_prims; i++) if (!always[i] && br[i] >= 0) n_bounded++;
+    h->n_bounded = n_bounded;
     const bool mf_reorder = h->mf_cull && n_bounded >= h->mf_min_bounded;
     const MfTable mt = mf_build_table(rec_file.data(), n_prims, cmax, mf_reorder);
     if (mt.reordered && mt.cmax > cmax) cmax = mt.cmax;
@@ -567,6 +569,7 @@ static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int
         kp.total_items = (unsigned)((uint64_t)rows * (uint64_t)h->width);
     }
     h->last_streams = stream_mode ? h->num_threads : 0;
+    h->accel_used = RT_ACCEL_SCAN;
     kp.rgb = d_rgb; kp.hit_ids = d_hit_ids;
     HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
@@ -647,7 +650,12 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     else if (h->broad_block == 256) e = broad_grid<256>(h, &bgrid);
     else e = broad_grid<512>(h, &bgrid);
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
-    const bool use_grid = h->accel && h->grid_ok;
+    // Where a ray's candidate solids come from.  Both sources hand the exact phase a superset of what it can accept, so the
+    // frame is the same bit for bit; left to the library the choice follows the measured crossover: the scan up to one LDS
+    // window of the binned kernel (32 groups = 1024 bounded solids; 4K room: 5.3 against 5.8 ms), the walk beyond it (1536
+    // solids 6.0 against 7.1 ms, 4096: 7.5 against 10.1, 6144: 8.5 against 12.3)
+    const bool use_grid = h->grid_ok && (h->accel == RT_ACCEL_WALK || (h->accel == RT_ACCEL_AUTO && h->n_bounded > h->accel_min_bounded));
+    h->accel_used = use_grid ? RT_ACCEL_WALK : RT_ACCEL_SCAN;
     // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
     const bool use_mfma = h->broad_mfma && !use_grid && h->d_frags;
     // one LDS window: its groups' fragments and those of its group records
@@ -675,7 +683,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     h->broad_ev_used = 0;
     if (h->timing_detail) {
         const size_t nb = (total + slots_cap[0] - 1) / slots_cap[0];
-        const size_t need = (size_t)2 * iters * (nb ? nb : 1);
+        const size_t need = (size_t)3 * iters * (nb ? nb : 1);       // per round: before the scan, between scan and shade_kernel, after
         while (h->broad_ev.size() < need) { hipEvent_t ev; HIP_TRY(h, hipEventCreate(&ev)); h->broad_ev.push_back(ev); }
     }
     HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
@@ -743,6 +751,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     if (it == 0) hipLaunchKernelGGL((shade_kernel<true, false>), sg, sb, shade_lds, ss[p], w);
                     else hipLaunchKernelGGL((shade_kernel<false, false>), sg, sb, shade_lds, ss[p], w);
                 }
+                if (h->timing_detail) HIP_TRY(h, hipEventRecord(h->broad_ev[h->broad_ev_used++], ss[p]));
             }
         }
         e = hipGetLastError();
@@ -809,15 +818,18 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     uint64_t r = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
     h->timing.kernel_ms = ms;
     h->timing.broad_ms = 0.0;
-    for (int i = 0; i + 1 < h->broad_ev_used; i += 2) {
-        float bms = 0;
+    h->timing.shade_ms = 0.0;
+    for (int i = 0; i + 2 < h->broad_ev_used; i += 3) {
+        float bms = 0, sms = 0;
         if (hipEventElapsedTime(&bms, h->broad_ev[i], h->broad_ev[i + 1]) == hipSuccess) h->timing.broad_ms += bms;
+        if (hipEventElapsedTime(&sms, h->broad_ev[i + 1], h->broad_ev[i + 2]) == hipSuccess) h->timing.shade_ms += sms;
     }
     h->timing.rays = r;
     h->timing.candidates = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
     h->timing.overflow_rays = ctrl[6];
     h->timing.broad_tiles = (uint64_t)ctrl[14] | ((uint64_t)ctrl[15] << 32);
     h->timing.broad_records = (uint64_t)h->n_groups * BROAD_GROUP;
+    h->timing.accel_used = (uint64_t)h->accel_used;
 #if WALK_DEBUG
     {
         unsigned dbg[8];

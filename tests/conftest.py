@@ -26,5 +26,15 @@ def renderer():
     library or the device is missing: the GPU tests must exercise the native path."""
     from raytracer_amd import api
     r = api.Renderer(0)
+    # the tests name the candidate source they look at; the library's own per-scene choice has a test of its own
+    r.set_option(api.OPT_ACCEL, api.ACCEL_SCAN)
     yield r
     r.close()
+
+
+@pytest.fixture(autouse=True)
+def _scan_unless_a_test_says_otherwise(monkeypatch):
+    """Contexts the tests create themselves take the scan of every record as their candidate source (RT_ACCEL=0 is read
+    by rt_create) unless a test sets the option: the tests name the source they look at.  The library's own per-scene
+    choice (RT_ACCEL_AUTO) has a test of its own, which removes the variable."""
+    monkeypatch.setenv("RT_ACCEL", "0")

@@ -108,3 +108,24 @@ def test_walk_full_size_equals_scan(renderer, cfg):
             assert total == rays0 and bits_equal(frame, rgb0).all()
     finally:
         renderer.set_option(api.OPT_ACCEL, 0)
+
+
+def test_library_picks_the_candidate_source_per_scene(monkeypatch):
+    """RT_ACCEL_AUTO (the default of a fresh context): the scan up to 1024 bounded solids, the grid walk beyond;
+    rt_timing.accel_used names the one that ran, and the frame is the same bit for bit either way."""
+    monkeypatch.delenv("RT_ACCEL", raising=False)
+    r = api.Renderer(0)
+    try:
+        for lattice, want in (((8, 8, 8), api.ACCEL_SCAN), ((16, 8, 8), api.ACCEL_SCAN), ((16, 10, 8), api.ACCEL_WALK)):
+            _, sc = synth.make("c3", width=192, lattice=lattice)
+            r.upload(sc)
+            auto = r.render(want_hits=True)
+            assert r.timing()["accel_used"] == want, lattice
+            r.set_option(api.OPT_ACCEL, api.ACCEL_WALK if want == api.ACCEL_SCAN else api.ACCEL_SCAN)
+            other = r.render(want_hits=True)
+            assert r.timing()["accel_used"] != want
+            r.set_option(api.OPT_ACCEL, api.ACCEL_AUTO)
+            assert auto["rays"] == other["rays"] and (auto["hits"] == other["hits"]).all()
+            assert np.array_equal(auto["rgb"].view(np.uint64), other["rgb"].view(np.uint64))
+    finally:
+        r.close()

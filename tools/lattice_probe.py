@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'/root/repo')
+import sys, time; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from raytracer_amd import api, synth
 lat = tuple(int(x) for x in sys.argv[1].split(','))

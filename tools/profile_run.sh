@@ -12,13 +12,13 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python $root/bench.py > $out/bench.json 2> $out/bench.err
 export RT_OVERLAP=1
-timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o vm -- python $root/bench.py --steps 5 --warmup 2 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/trace.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/pmc_fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/pmc_write.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/pmc_sq.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 --output-format csv -d $out/pmc_sq2 -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/pmc_sq2.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq3 -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/pmc_sq3.log 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o vm -- python $root/bench.py --steps 5 --warmup 2 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/pmc_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 --output-format csv -d $out/pmc_sq2 -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/pmc_sq2.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq3 -o vm -- python $root/bench.py --steps 1 --warmup 0 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/pmc_sq3.log 2>&1
 # the same frames with candidate solids from the grid walk (RT_ACCEL=1 makes it the context's default)
-RT_ACCEL=1 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_walk -o vm -- python $root/bench.py --steps 5 --warmup 2 --roofline-frames 0 --no-cpu-baseline --no-walk > $out/trace_walk.log 2>&1
+RT_ACCEL=1 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_walk -o vm -- python $root/bench.py --steps 5 --warmup 2 --roofline-frames 0 --no-cpu-baseline --no-walk --no-in-contract > $out/trace_walk.log 2>&1
 unset RT_OVERLAP
 cat $out/bench.json

@@ -64,9 +64,15 @@ if st:
     for (k, c), v in sorted(st.items()):
         if 'rocclr' in k or k.startswith('at::'): continue
         lines.append('| %s | %s | %.4g |' % (k, c, v))
-for k in traffic:          # VALU wave-instructions per frame (bench.py: roofline.valu_issue_frac)
-    v = st.get((k, 'SQ_INSTS_VALU'))
-    if v is not None: traffic[k]['valu_insts'] = v
+# counters bench.py reads back: VALU wave-instructions (roofline.valu_issue_frac), FP64 add / mul / fma wave-instructions
+# (executed FLOP of shade_kernel), lanes active per VALU instruction, SALU share
+for k in traffic:
+    for key, counter in (('valu_insts', 'SQ_INSTS_VALU'), ('fp64_add', 'SQ_INSTS_VALU_ADD_F64'), ('fp64_mul', 'SQ_INSTS_VALU_MUL_F64'),
+                         ('fp64_fma', 'SQ_INSTS_VALU_FMA_F64'), ('thread_cycles_valu', 'SQ_THREAD_CYCLES_VALU'),
+                         ('active_inst_valu', 'SQ_ACTIVE_INST_VALU'), ('salu_insts', 'SQ_INSTS_SALU'), ('insts', 'SQ_INSTS'),
+                         ('mfma_insts', 'SQ_INSTS_MFMA'), ('wave_cycles', 'SQ_WAVE_CYCLES'), ('wait_inst_any', 'SQ_WAIT_INST_ANY')):
+        v = st.get((k, counter))
+        if v is not None: traffic[k][key] = v
 open(os.path.join(dst, prefix + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
 json.dump({'source': prefix, 'workload': bench.get('config', {}).get('workload'), 'note': 'HBM bytes per frame and kernel: (2 x FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes',
            'kernels': traffic}, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
