@@ -841,8 +841,10 @@ int rt_finish(rt_handle h, uint64_t* rays) {
     {
         unsigned long long prof[6];
         hipMemcpy(prof, h->d_ctrl + 16, sizeof(prof), hipMemcpyDeviceToHost);
-        fprintf(stderr, "shade wave-cycles: loop-top %llu  load_state %llu  find_hit %llu  segment %llu  barriers %llu  emit %llu\n",
-                prof[0], prof[5], prof[1], prof[2], prof[3], prof[4]);
+        unsigned rc[2];
+        hipMemcpy(rc, h->d_ctrl + 30, sizeof(rc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "shade wave-cycles: loop-top %llu  find_hit %llu  segment %llu  retry pool %llu  barriers %llu  emit %llu   (waves with a rejected sample %u, such rays %u)\n",
+                prof[0], prof[1], prof[2], prof[5], prof[3], prof[4], rc[0], rc[1]);
     }
 #endif
     h->timing.sphere_tests = r * h->n_spheres;

@@ -156,33 +156,128 @@ DEV d3 rotate3(d3 v, d3 n, double cost, double sint) {
     return dadd(dadd(a, b), c);
 }
 
-// get_reflection_ray, main.cpp:47-104.  Returns the new direction (not re-normalised).  The glossy
-// branch (:48-77, power-cosine lobe about the mirror direction, rejection loop) and the diffuse branch
-// (:78-103, uniform hemisphere about the normal) build their sample the same way about different axes;
-// they share one instruction stream here, each lane keeping its own branch's operation sequence.
-DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double inv_exp, unsigned& rng, unsigned* err, unsigned item) {
+// what one sample of the reflection lobe needs beyond the RNG state: the rotation that carries +z to the lobe's axis (unit
+// axis n, angle theta: main.cpp:53-59,80-86), 1 / specular_exp, and whether the surface normal is (0, 0, 1) within 1e-4
+// (the reference tests the NORMAL there, main.cpp:68,95)
+struct LobeCtx { d3 n; double cost, sint, inv_exp; bool flat; };
+
+// One sample (main.cpp:62-73, 89-100): two draws, the +z hemisphere sample, the rotation.  glossy: power-cosine lobe,
+// else uniform hemisphere; both build their sample the same way and share this instruction stream, each lane keeping
+// its own branch's operation sequence.
+DEV d3 lobe_sample(bool glossy, const LobeCtx& c, unsigned& rng) {
     const double PI = 3.14159265358979323846;
-    const bool flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
+    const double u1 = rng_uniform(rng);
+    const double u = glossy ? rtm::powd(rtm::cosd(u1 * PI / 2.0), c.inv_exp) : u1;
+    const double phi = rng_uniform(rng) * 2.0 * PI;
+    const double sr = __builtin_sqrt(1.0 - u * u);
+    double sp, cp;
+    rtm::sincosd(phi, &sp, &cp);
+    const d3 v = dmk(sr * cp, sr * sp, u);
+    return c.flat ? v : rotate3(v, c.n, c.cost, c.sint);
+}
+
+// get_reflection_ray, main.cpp:47-104.  Returns the new direction (not re-normalised).  The glossy branch (:48-77,
+// power-cosine lobe about the mirror direction, rejection loop until the sample points away from the surface) and the
+// diffuse branch (:78-103, uniform hemisphere about the normal, no rejection).
+// POOL = false: the rejection loop runs here, as in the reference.  POOL = true: ONE sample is drawn; if it is rejected,
+// *pending is set, *ctx holds what further samples need, and the caller draws them (lobe_retry_pool): a wave then spends
+// its lanes on the few rays that still draw instead of repeating the loop body for them alone.
+template <bool POOL>
+DEV d3 reflection_dir(d3 d, d3 normal, unsigned gloss_thr, double inv_exp, unsigned& rng, unsigned* err, unsigned item,
+                      LobeCtx* ctx, bool* pending) {
+    LobeCtx c;
+    c.flat = __builtin_fabs(normal.z - 1.0) < 0.0001;
+    c.inv_exp = inv_exp;
     const bool glossy = rng_next(rng) < gloss_thr;
     const d3 axis = glossy ? dneg(reflect_dir(d, normal)) : normal;
     const double theta = rtm::acosd(axis.z);
-    const d3 n = dnorm(dcross(dmk(0.0, 0.0, 1.0), axis));
-    double sint, cost;
-    rtm::sincosd(theta, &sint, &cost);
+    c.n = dnorm(dcross(dmk(0.0, 0.0, 1.0), axis));
+    rtm::sincosd(theta, &c.sint, &c.cost);
     d3 nd = dmk(0.0, 0.0, 0.0);
     for (int iter = 0;; iter++) {
-        const double u1 = rng_uniform(rng);
-        const double u = glossy ? rtm::powd(rtm::cosd(u1 * PI / 2.0), inv_exp) : u1;
-        const double phi = rng_uniform(rng) * 2.0 * PI;
-        const double sr = __builtin_sqrt(1.0 - u * u);
-        double sp, cp;
-        rtm::sincosd(phi, &sp, &cp);
-        const d3 v = dmk(sr * cp, sr * sp, u);
-        nd = flat ? v : rotate3(v, n, cost, sint);
+        nd = lobe_sample(glossy, c, rng);
         if (!glossy || ddot(nd, normal) >= 0.0) break;
+        if (POOL) { *ctx = c; *pending = true; break; }
         if (iter > REJECT_GUARD_ITERS) { atomicOr(err, ERR_REJECT_GUARD); atomicMax(err + 6, item + 1u); break; }
     }
     return nd;
+}
+
+// 16807^(2k) mod (2^31 - 1), k = 0 .. 64: the generator's state after 2k further draws is state * that (mod 2^31 - 1)
+struct RngJump {
+    unsigned v[65];
+    constexpr RngJump() : v{} {
+        unsigned long long x = 1;
+        for (int k = 0; k <= 64; k++) { v[k] = (unsigned)x; x = x * 16807ull % 2147483647ull; x = x * 16807ull % 2147483647ull; }
+    }
+};
+__device__ const RngJump RNG_JUMP = RngJump();
+// s * m mod (2^31 - 1) for a state s in [1, 2^31 - 2] and a multiplier below 2^31, by folding the product twice
+// (2^31 == 1 mod 2^31 - 1); the result is a state again (never 0: neither factor is a multiple of the prime)
+DEV unsigned rng_mulmod(unsigned s, unsigned m) {
+    const unsigned long long p = (unsigned long long)s * m;
+    unsigned long long x = (p & 0x7fffffffull) + (p >> 31);
+    x = (x & 0x7fffffffull) + (x >> 31);
+    if (x >= 0x7fffffffull) x -= 0x7fffffffull;
+    return (unsigned)x;
+}
+// lane index of the k-th set bit (k < popcount) of a wave-uniform 64-bit mask
+DEV int nth_set_bit(unsigned long long mask, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long low = mask & ((1ull << w) - 1ull);
+        const int c = __popcll(low);
+        const bool up = k >= c;
+        k = up ? k - c : k;
+        mask = up ? mask >> w : low;
+        pos = up ? pos + w : pos;
+    }
+    return pos;
+}
+
+// The further samples of the rejection loop (main.cpp:61-76) for the rays of a wave whose first sample was rejected, drawn
+// by the WHOLE wave (call it with every lane active).  Sample j of a ray is a pure function of the lobe and of the RNG
+// state after 2j draws, and that state is the ray's state times a constant (RNG_JUMP): so the R rays that still draw are
+// dealt K = 64 / R lanes each, lane a of a ray's share draws its sample number a, and the ray takes the first accepted one
+// with the RNG state that goes with it -- the values the loop would have reached one sample at a time.  A ray none of whose
+// K samples was accepted moves its state 2K draws on and goes round again.
+//   need: this lane's ray still draws; c, normal: its lobe and surface normal; rng: its state after the rejected sample;
+//   dir: receives the accepted sample.
+DEV void lobe_retry_pool(bool need, const LobeCtx& c, d3 normal, unsigned& rng, d3& dir, unsigned* err, unsigned item) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long mask = __ballot(need);
+    int tries = 0;
+    while (mask) {
+        const int R = __popcll(mask), K = 64 / R;
+        const int i = lane / K, a = lane - i * K;
+        const bool work = i < R;
+        const int src = nth_set_bit(mask, work ? i : 0);
+        LobeCtx q;
+        q.n = dmk(__shfl(c.n.x, src, 64), __shfl(c.n.y, src, 64), __shfl(c.n.z, src, 64));
+        q.cost = __shfl(c.cost, src, 64); q.sint = __shfl(c.sint, src, 64); q.inv_exp = __shfl(c.inv_exp, src, 64);
+        q.flat = __shfl((int)c.flat, src, 64) != 0;
+        const d3 qn = dmk(__shfl(normal.x, src, 64), __shfl(normal.y, src, 64), __shfl(normal.z, src, 64));
+        unsigned qr = rng_mulmod((unsigned)__shfl((int)rng, src, 64), RNG_JUMP.v[a]);
+        const d3 nd = lobe_sample(true, q, qr);
+        const bool ok = work && ddot(nd, qn) >= 0.0;
+        const unsigned long long okm = __ballot(ok);
+        // the owner: its share is lanes [rank K, rank K + K)
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long share = need ? (okm >> (rank * K)) & (K == 64 ? ~0ull : ((1ull << K) - 1ull)) : 0ull;
+        const bool got = share != 0ull;
+        const int from = got ? rank * K + __builtin_ctzll(share) : lane;
+        const d3 take = dmk(__shfl(nd.x, from, 64), __shfl(nd.y, from, 64), __shfl(nd.z, from, 64));
+        const unsigned take_rng = (unsigned)__shfl((int)qr, from, 64);
+        if (got) { dir = take; rng = take_rng; need = false; }
+        else if (need) rng = rng_mulmod(rng, RNG_JUMP.v[K]);
+        tries += K;
+        if (tries > REJECT_GUARD_ITERS) {
+            if (need) { atomicOr(err, ERR_REJECT_GUARD); atomicMax(err + 6, item + 1u); }
+            break;
+        }
+        mask = __ballot(need);
+    }
 }
 
 // get_refraction_ray, main.cpp:107-122, with Line::reflect / Line::refract, geometry.cpp:78-92

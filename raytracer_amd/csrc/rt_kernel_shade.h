@@ -104,7 +104,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     __syncthreads();
 #if SHADE_PROFILE
     // wave-cycles per section (find_hit | segment | barriers | emit), summed over waves into ctrl[16..]
-    unsigned long long prof[5] = {0, 0, 0, 0, 0};
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tick = __builtin_amdgcn_s_memtime();
 #define SHADE_TICK(k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); prof[k] += now - tick; tick = now; }
 #else
@@ -121,7 +121,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     for (unsigned t = 0; t < trips; t++) {
         const unsigned pos = t * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool live = pos < count;
-        bool alive = false;
+        bool alive = false, retry = false;
+        LobeCtx lobe;
+        lobe.n = dmk(0, 0, 0); lobe.cost = lobe.sint = lobe.inv_exp = 0.0; lobe.flat = false;
         PathState s;
         unsigned slot = 0;
         SHADE_TICK(0);
@@ -158,9 +160,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             }
             nrays++;
             FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
-            alive = segment(s, h, fst, w.item_base + slot, 0ull, w.kp);
+            alive = segment<true>(s, h, fst, w.item_base + slot, 0ull, w.kp, &lobe, &retry);
         }
+#if SHADE_PROFILE
+        { const unsigned long long rm = __ballot(retry); if (lane == 0 && rm) { atomicAdd(&w.kp.ctrl[30], 1u); atomicAdd(&w.kp.ctrl[31], (unsigned)__popcll(rm)); } }
+#endif
+        // glossy samples that were rejected (main.cpp:61-76): the whole wave draws the further samples of its few such rays
         SHADE_TICK(2);
+        lobe_retry_pool(retry, lobe, s.pv_n, s.rng, s.d, &w.kp.ctrl[1], w.item_base + slot);
+        SHADE_TICK(5);
         // pack the surviving rays into the next queue: rank within the wave's ballot, the waves' survivor counts
         // meet in LDS (double-buffered by trip parity) and the workgroup takes its range with ONE atomic --
         // an atomic per wave on the one counter costs more than a millisecond per frame
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         SHADE_TICK(4);
     }
 #if SHADE_PROFILE
-    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)(w.kp.ctrl + 16 + 2 * k), prof[k]);
+    if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd((unsigned long long*)(w.kp.ctrl + 16 + 2 * k), prof[k]);
 #endif
     // ray and candidate totals: wave sums through LDS, one atomic pair per workgroup
     unsigned long long r = nrays, cn = ncand_total;

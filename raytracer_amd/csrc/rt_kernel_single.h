@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const KParams kp) {
         if (alive) {
             nrays++;
             item_rays++;
-            if (!segment(s, h, fst, item, item_rays, kp)) state = ST_NEED;
+            if (!segment<false>(s, h, fst, item, item_rays, kp)) state = ST_NEED;
         }
     }
 

@@ -101,9 +101,12 @@ DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, 
 // One segment of add_to_path (main.cpp:126-183) after its closest hit `h` is known: record the hit id
 // of a camera ray, push the previous vertex's throughput factor (Path::trace, geometry.cpp:190-213),
 // then terminate the path or sample the next ray.  Returns false when the lane's item is finished.
-template <class FStack>
+// POOL: the caller draws the further samples of a rejected glossy sample (lobe_retry_pool) -- *retry is then set and *lobe
+// filled; the state already holds everything else of the new ray (s.pv_n is the surface normal the samples are tested
+// against).  Without POOL the rejection loop runs inside.
+template <bool POOL, class FStack>
 DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, unsigned long long item_rays,
-                 const KParams& kp) {
+                 const KParams& kp, LobeCtx* lobe = nullptr, bool* retry = nullptr) {
     if (s.flags & FL_FIRST_SEG) {
         if (kp.hit_ids) kp.hit_ids[(size_t)s.out_index * kp.spp + s.sample] = h.idx;
         s.flags &= ~FL_FIRST_SEG;
@@ -173,7 +176,7 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         const bool leaving = __builtin_fabs(rindex - s.n_cur) < 0.0001;
         if (!leaving) reflect = rindex == 0.0 || rng_next(s.rng) < 1073741823u;        // main.cpp:164-167: no draw for an opaque solid
         if (reflect) {
-            fwd = reflection_dir(s.d, normal, gloss_thr, m->inv_sexp, s.rng, &kp.ctrl[1], item);
+            fwd = reflection_dir<POOL>(s.d, normal, gloss_thr, m->inv_sexp, s.rng, &kp.ctrl[1], item, lobe, retry);
         } else {
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
             if (leaving) change = 0; else n2 = rindex;
