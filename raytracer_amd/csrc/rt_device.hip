@@ -112,7 +112,7 @@ int rt_create(rt_handle* out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return RT_ERR_NO_DEVICE; }
     h->cu_count = prop.multiProcessorCount;
-    if (hipMalloc((void**)&h->d_ctrl, 256) != hipSuccess) { delete h; return RT_ERR_HIP; }
+    if (hipMalloc((void**)&h->d_ctrl, RT_CTRL_BYTES) != hipSuccess) { delete h; return RT_ERR_HIP; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
@@ -571,7 +571,7 @@ static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int
     h->last_streams = stream_mode ? h->num_threads : 0;
     h->accel_used = RT_ACCEL_SCAN;
     kp.rgb = d_rgb; kp.hit_ids = d_hit_ids;
-    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, RT_CTRL_BYTES, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (kp.total_items > 0) {
         hipError_t e;
@@ -686,7 +686,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         const size_t need = (size_t)3 * iters * (nb ? nb : 1);       // per round: before the scan, between scan and shade_kernel, after
         while (h->broad_ev.size() < need) { hipEvent_t ev; HIP_TRY(h, hipEventCreate(&ev)); h->broad_ev.push_back(ev); }
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, 256, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_ctrl, 0, RT_CTRL_BYTES, st));
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     hipStream_t ss[RT_MAX_SUB] = {st, st, st};
     if (nsub > 1) {
@@ -843,6 +843,15 @@ int rt_finish(rt_handle h, uint64_t* rays) {
         hipMemcpy(prof, h->d_ctrl + 16, sizeof(prof), hipMemcpyDeviceToHost);
         unsigned rc[2];
         hipMemcpy(rc, h->d_ctrl + 30, sizeof(rc), hipMemcpyDeviceToHost);
+        {   // lanes active where a section of the kernel is entered (PROF_LANES points), summed over the frame's launches
+            unsigned long long la[2 * 24];
+            hipMemcpy(la, h->d_ctrl + 64, sizeof(la), hipMemcpyDeviceToHost);
+            static const char* names[24] = {"candidate test", "always tests", "segment", "sphere normal", "plane material", "factor", "factor pow",
+                                            "light product step", "dead end", "reflect", "refract", "end_path", "emit", "heavy ray", "retry pass", "state load",
+                                            "list scan step", "", "", "", "", "", "", ""};
+            for (int k = 0; k < 24; k++)
+                if (la[2 * k + 1]) fprintf(stderr, "  lanes %-20s entries %10llu  mean active %5.1f of 64\n", names[k], la[2 * k + 1], (double)la[2 * k] / (double)la[2 * k + 1]);
+        }
         fprintf(stderr, "shade wave-cycles: loop-top %llu  find_hit %llu  segment %llu  retry pool %llu  barriers %llu  emit %llu   (waves with a rejected sample %u, such rays %u)\n",
                 prof[0], prof[1], prof[2], prof[5], prof[3], prof[4], rc[0], rc[1]);
     }

@@ -252,6 +252,7 @@ DEV void lobe_retry_pool(bool need, const LobeCtx& c, d3 normal, unsigned& rng, 
         const int R = __popcll(mask), K = 64 / R;
         const int i = lane / K, a = lane - i * K;
         const bool work = i < R;
+        if (work) { PROF_LANES(err - 1, 14); }
         const int src = nth_set_bit(mask, work ? i : 0);
         LobeCtx q;
         q.n = dmk(__shfl(c.n.x, src, 64), __shfl(c.n.y, src, 64), __shfl(c.n.z, src, 64));

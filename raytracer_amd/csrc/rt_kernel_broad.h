@@ -12,9 +12,6 @@ namespace {
 //                                   next queue by ballot rank (one atomic per wave)
 // until a queue is empty.  Each kernel gets its own register allocation: the hot broad_kernel stays
 // small and runs at high occupancy, the branchy double-precision shade_kernel may use what it needs.
-#ifndef SHADE_PROFILE
-#define SHADE_PROFILE 0
-#endif
 #ifndef DIAG_TWICE_ALWAYS      // diagnostic builds: run a section of shade_kernel twice
 #define DIAG_TWICE_ALWAYS 0
 #endif

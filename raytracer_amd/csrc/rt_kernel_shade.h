@@ -37,6 +37,7 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
         if (n > 0u) cur = cl[0];
         if (n > 1u) nxt = cl[cstride];
         // a ray the box entries' test is not proven for joins the heavy rays: every solid through the general test
+        PROF_LANES(w.kp.ctrl, 1);
         heavy = narrow_always<false>(alw, w.kp.n_always, w.kp.n_box, o, d, w.kp, h);
 #if DIAG_TWICE_ALWAYS      // diagnostic build: the section's cost is the frame time it adds (re-considering a hit changes nothing)
         __builtin_amdgcn_sched_barrier(0);
@@ -53,7 +54,9 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
             if (e + 2u < n) nxt = cl[(e + 2u) * cstride];
             unsigned m = ent.y;
             ncand_total += (unsigned)__popc(m);
+            PROF_LANES(w.kp.ctrl, 16);
             while (m) {
+                PROF_LANES(w.kp.ctrl, 0);
                 const int k = __clz((int)m);
                 m &= ~(0x80000000u >> k);
                 // a ray with a NaN direction makes every s NaN and thr - NaN negative, padding records
@@ -74,6 +77,7 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
         Hit hl;
         hl.q = __builtin_inf(); hl.idx = -1;
         hl.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
+        PROF_LANES(w.kp.ctrl, 13);
         for (int i = lane; i < w.kp.n_prims; i += 64) narrow_one(i, ob, db, w.kp, hl);
         for (int off = 32; off > 0; off >>= 1) {
             const double oq = __shfl_xor(hl.q, off, 64);
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
                 s.o = ro; s.d = rd; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
                 s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
             } else {
+                PROF_LANES(w.kp.ctrl, 15);
                 slot = w.queue[qi][pos];
                 load_state(w, qi, pos, slot, ro, rd, s);
             }
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         unsigned base = wg_base[t & 1];
         for (int k = 0; k < wv; k++) base += cnt[k];
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (alive) { PROF_LANES(w.kp.ctrl, 12); }
         if (alive) emit_ray(w, base + rank, slot, s, qo);
         SHADE_TICK(4);
     }

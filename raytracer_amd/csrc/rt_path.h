@@ -111,6 +111,7 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         if (kp.hit_ids) kp.hit_ids[(size_t)s.out_index * kp.spp + s.sample] = h.idx;
         s.flags &= ~FL_FIRST_SEG;
     }
+    PROF_LANES(kp.ctrl, 2);
     if (h.idx < 0) return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);           // main.cpp:179-182
     const PrimD* pi = kp.prims + h.idx;
     const int4 ids = ldi4(&pi->kind);                  // kind, mat0, mat1, voff
@@ -118,11 +119,13 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     d3 normal;
     int mi = ids.y;
     if (kind == RT_KIND_SPHERE) {
+        PROF_LANES(kp.ctrl, 3);
         const double2 a01 = ld2(pi->a), a2r = ld2(pi->a + 2);
         normal = dnorm(dsub(h.p, dmk(a01.x, a01.y, a2r.x)));
     } else {
         const double2 n01 = ld2(pi->n), n2p = ld2(pi->n + 2);
         normal = dmk(n01.x, n01.y, n2p.x);
+        if (kind == RT_KIND_PLANE) { PROF_LANES(kp.ctrl, 4); }
         if (kind == RT_KIND_PLANE) mi = plane_material(pi->a[0], pi->a[2], ids.y, ids.z, h.p);
     }
     const MatD* m = kp.mats + mi;
@@ -133,12 +136,14 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     const bool dead_end = (!is_light) && s.remaining == 0 && kp.has_light;             // main.cpp:137-153: always black
 
     if (s.nverts > 0 && !dead_end) {
+        PROF_LANES(kp.ctrl, 5);
         const MatD* pm = kp.mats + s.pv_mat;
         d3 w = dnorm(dsub(h.p, s.o));
         double sp;
         const bool pv_reflect = (s.flags & FL_PV_REFLECT) != 0;
         const double* cs = pv_reflect ? pm->diff : pm->rdiff;       // (diffuse, specular) or the refraction pair
         const double2 c01 = ld2(cs), c2s0 = ld2(cs + 2), s12 = ld2(cs + 4);
+        if (pv_reflect) { PROF_LANES(kp.ctrl, 6); }
         if (pv_reflect) sp = rtm::powd(ddot(s.pv_r, w), pm->sexp);
         else sp = 1.0;
         double dd = ddot(s.pv_n, w);
@@ -155,12 +160,14 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         const double2 e01 = ld2(m->ref), e2 = ld2(m->ref + 2);       // (ref0, ref1), (ref2, -)
         c0 = e01.x; c1 = e01.y; c2 = e2.x;
         for (int k = s.nverts - 1; k >= 0; k--) {
+            PROF_LANES(kp.ctrl, 7);
             double f0, f1, f2;
             fst.get3(k, f0, f1, f2);
             c0 = c0 * f0; c1 = c1 * f1; c2 = c2 * f2;
         }
         term = true;
     } else if (dead_end) {
+        PROF_LANES(kp.ctrl, 8);
         for (int k = 0; k < kp.light_draws; k++) rng_next(s.rng);                      // rand_point of the first light
         term = true;
     } else if (s.nverts >= kp.max_verts) {
@@ -176,8 +183,10 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         const bool leaving = __builtin_fabs(rindex - s.n_cur) < 0.0001;
         if (!leaving) reflect = rindex == 0.0 || rng_next(s.rng) < 1073741823u;        // main.cpp:164-167: no draw for an opaque solid
         if (reflect) {
+            PROF_LANES(kp.ctrl, 9);
             fwd = reflection_dir<POOL>(s.d, normal, gloss_thr, m->inv_sexp, s.rng, &kp.ctrl[1], item, lobe, retry);
         } else {
+            PROF_LANES(kp.ctrl, 10);
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
             if (leaving) change = 0; else n2 = rindex;
         }
@@ -188,6 +197,7 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         s.nverts++;
         s.o = h.p; s.d = fwd; s.remaining -= change; s.n_cur = n2;
     }
+    if (term) { PROF_LANES(kp.ctrl, 11); }
     if (term) return end_path(s, c0, c1, c2, item, item_rays, kp);
     return true;
 }

@@ -13,6 +13,18 @@ constexpr unsigned ERR_REJECT_GUARD = 1u, ERR_STACK = 2u;
 constexpr int REJECT_GUARD_ITERS = 1 << 20;
 constexpr float F32_U = 5.9604645e-8f;         // 2^-24, unit roundoff of float
 
+constexpr int RT_CTRL_BYTES = 1024;           // the control block: words 0..63 as listed at KParams::ctrl, 64.. profile counters
+// SHADE_PROFILE builds: lanes active at point k of shade_kernel (sum, entries) as two u64 at ctrl + 64 + 4k
+#ifndef SHADE_PROFILE
+#define SHADE_PROFILE 0
+#endif
+#if SHADE_PROFILE
+#define PROF_LANES(ctrl, k) { const unsigned long long pm_ = __ballot(1); if ((int)(threadIdx.x & 63) == __builtin_ctzll(pm_)) { \
+    atomicAdd((unsigned long long*)((ctrl) + 64 + 4 * (k)), (unsigned long long)__popcll(pm_)); atomicAdd((unsigned long long*)((ctrl) + 66 + 4 * (k)), 1ull); } }
+#else
+#define PROF_LANES(ctrl, k)
+#endif
+
 struct ChunkDesc { int gofs, count, first_index, pad; };   // count: records incl. NaN padding to a multiple of 32
 
 // The exact phase reads these tables lane by lane at unrelated addresses (each lane its own solid or material), and
