@@ -62,6 +62,17 @@ struct WfParams {
     unsigned* cand_cnt;        // [2][slots] (one per queue: a round's shade_kernel reads one and clears the other) entries used; above WF_CAND_CAP (WF_OVERFLOW as a rule): more non-zero words than fit
 };
 
+// A kernel's parameters seen through the kernel-argument segment (WfParams is the kernels' first argument: offset 0),
+// behind a pointer the compiler cannot see through: what a section of a kernel needs of them is then loaded (scalar
+// loads) where the section begins, instead of sitting in SGPRs -- and, for want of those, in spilled lanes -- for a whole
+// trip of the kernel's loop.
+typedef const WfParams __attribute__((address_space(4)))* WfKargPtr;
+DEV const WfParams& karg_view() {
+    WfKargPtr p = (WfKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const WfParams*)p;
+}
+
 // the ray itself (o, d) was read before the closest-hit search and is passed in
 DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, d3 ro, d3 rd, PathState& s) {
     const size_t n = w.slots;

@@ -363,9 +363,16 @@ constexpr int MFB_GROUPS = 32;                 // groups per window for this ker
 constexpr int MFB_LIST = 192;                  // places in a group's ray list; a group more rays than that keep is scanned for all
                                                // (list_cap <= MFB_LIST: the number in use, lower in tests of that path)
 
+#ifndef MFB_KARG
+#define MFB_KARG 1          // 0: the parameters as the compiler keeps them (7 spilled VGPRs)
+#endif
+#ifndef MFB_WRITELANE
+#define MFB_WRITELANE 1     // 0: the ballot words reach their lanes through compare + select
+#endif
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap) {
+__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w_arg, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap) {
     extern __shared__ uint4 mf_lds[];
+    const WfParams& w = w_arg;
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
     constexpr unsigned SKIP = 0xffffffffu;
     const unsigned count = w.counts[w.iter];
@@ -383,7 +390,6 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
     unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * MFB_LIST);
     unsigned* const gcount2 = rcnt + RAYS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
-    const size_t cstride = w.slots;
     unsigned pass = 0, tiles_done = 0;                     // (32 rays x 32 records) products of this wave
     for (int win = 0; win < n_windows; win++) {
         const int g0 = win * win_groups;
@@ -399,7 +405,12 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const unsigned pos = batch * RAYS + local;
             const bool valid = pos < count;
             const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
-            const float4 ra = valid ? w.rec[0][pos] : none, rb = valid ? w.rec[1][pos] : none;
+#if MFB_KARG
+            const WfParams& wa = karg_view();
+#else
+            const WfParams& wa = w_arg;
+#endif
+            const float4 ra = valid ? wa.rec[0][pos] : none, rb = valid ? wa.rec[1][pos] : none;
             const bool ordinary = mf_ordinary(ra, rb, scale);
             const RayFrag rf = mf_ray_frag(ra, rb, scale, h, ordinary);
             F16Pack p0, p1;
@@ -430,7 +441,15 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
 #pragma unroll
             for (int k = 0; k < 32; k++) {
                 const unsigned b = (unsigned)__ballot((gm & (0x80000000u >> k)) != 0u);     // (upper lane half: gm = 0)
+#if MFB_WRITELANE
+                // The word goes straight into lane k: one instruction, and no SGPR pair stays live per group (the select form
+                // kept all 32 ballots in SGPRs: 62 of them spilled).  The wait states are needed -- the ballot's SGPR was
+                // written by a vector compare; without them the lane received a stale word on the hardware -- and the
+                // compiler inserts none inside an asm statement (5 covers every VALU-writes-SGPR case of the ISA manual).
+                asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(bw) : "s"(b), "i"(k));
+#else
                 if (lane == k) bw = b;
+#endif
             }
             // lane k enters group k's rays of this wave in the group's list (places past the list's end stay unwritten:
             // the group is then scanned for all rays of the pass)
@@ -458,6 +477,13 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
             if (threadIdx.x < MFB_GROUPS) gcount2[((pass & 1u) ^ 1u) * MFB_GROUPS + threadIdx.x] = 0u;     // the next pass's counters
             tiles_done += 1u + (total > (unsigned)wv ? (total - (unsigned)wv + NW - 1u) / NW : 0u);      // group records + this wave's items
+#if MFB_KARG
+            const WfParams& wc = karg_view();
+#else
+            const WfParams& wc = w_arg;
+#endif
+            uint2* const cand = wc.cand;
+            const size_t cstride = wc.slots;
             for (unsigned item = (unsigned)wv; item < total; item += NW) {     // items cost the same: dealt out in turn
                 const unsigned long long in = __ballot(lane < 32 && start <= item && item < incl);
                 const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
@@ -480,7 +506,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 // (a ray without a list of its own -- none here, not ordinary -- has zero fragments, but its rcnt says SKIP)
                 if (h == 0 && have && full != 0u && rcnt[id] != SKIP) {
                     const unsigned at = atomicAdd(&rcnt[id], 1u);
-                    if (at < (unsigned)WF_CAND_CAP) w.cand[(size_t)at * cstride + (batch * RAYS + id)] = make_uint2((unsigned)(g0 + g), full);
+                    if (at < (unsigned)WF_CAND_CAP) cand[(size_t)at * cstride + (batch * RAYS + id)] = make_uint2((unsigned)(g0 + g), full);
                 }
             }
             __syncthreads();                                   // every item is done

@@ -99,9 +99,19 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
 // lane rebuilds from the pixel index (the same operations as init_kernel, hence the same bits) instead of reading it:
 // init_kernel then writes 36 bytes per pixel instead of 152 and this round reads none of them back.
 // PLACES: the candidate lists name places of the matrix-core scan's own record order (narrow_place).
+#ifndef SHADE_KARG
+#define SHADE_KARG 1        // 0: the parameters as the compiler keeps them (113 to 120 spilled SGPRs, 13 to 16 spilled VGPRs; C3 frame +0.2 ms)
+#endif
+#if SHADE_KARG
+#define SHADE_VIEW(name) const WfParams& name = karg_view()
+#else
+#define SHADE_VIEW(name) const WfParams& name = w_arg
+#endif
+
 template <bool FIRST, bool PLACES>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void shade_kernel(const WfParams w_arg) {
     extern __shared__ double alw[];
+    const WfParams& w = w_arg;
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     for (int i = threadIdx.x; i < w.kp.always_doubles; i += SHADE_BLOCK) alw[i] = w.kp.always[i];
@@ -134,38 +144,41 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
         d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
         unsigned rng0 = 0;
+        SHADE_VIEW(w1);
         if (FIRST) {
             if (live) {
                 // only the ray and the RNG state stay in registers during the closest-hit search
                 PathState t0;
                 slot = pos;
-                start_state(w, slot, t0);
+                start_state(w1, slot, t0);
                 ro = t0.o; rd = t0.d; rng0 = t0.rng;
             }
         } else if (live) {
-            const double2* sd = w.sd[qi] + pos;
-            const size_t n = w.slots;
+            const double2* sd = w1.sd[qi] + pos;
+            const size_t n = w1.slots;
             const double2 p0 = sd[0], p1 = sd[n], p2 = sd[2 * n];
             ro = dmk(p0.x, p0.y, p1.x);
             rd = dmk(p1.y, p2.x, p2.y);
         }
-        const Hit h = find_hit<PLACES>(w, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
+        SHADE_VIEW(w2);
+        const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
+        SHADE_VIEW(w3);
         if (live) {
             if (FIRST) {
-                map_item_to_pixel(w.item_base + slot, w.kp, s.px, s.py);
-                s.rng = rng0; s.sample = 0; s.remaining = w.kp.depth; s.nverts = 0; s.pv_mat = 0; s.flags = FL_FIRST_SEG;
-                s.out_index = w.item_base + slot; s.n_cur = 1.0; s.acc0 = s.acc1 = s.acc2 = 0.0;
+                map_item_to_pixel(w3.item_base + slot, w3.kp, s.px, s.py);
+                s.rng = rng0; s.sample = 0; s.remaining = w3.kp.depth; s.nverts = 0; s.pv_mat = 0; s.flags = FL_FIRST_SEG;
+                s.out_index = w3.item_base + slot; s.n_cur = 1.0; s.acc0 = s.acc1 = s.acc2 = 0.0;
                 s.o = ro; s.d = rd; s.pv_n = dmk(0, 0, 0); s.pv_r = dmk(0, 0, 0);
-                s.acc_mem = w.acc + slot; s.acc_stride = w.slots;
+                s.acc_mem = w3.acc + slot; s.acc_stride = w3.slots;
             } else {
-                PROF_LANES(w.kp.ctrl, 15);
-                slot = w.queue[qi][pos];
-                load_state(w, qi, pos, slot, ro, rd, s);
+                PROF_LANES(w3.kp.ctrl, 15);
+                slot = w3.queue[qi][pos];
+                load_state(w3, qi, pos, slot, ro, rd, s);
             }
             nrays++;
-            FactorStackV fst; fst.base = w.stack + (size_t)slot * 4u * (unsigned)w.kp.max_verts;
-            alive = segment<true>(s, h, fst, w.item_base + slot, 0ull, w.kp, &lobe, &retry);
+            FactorStackV fst; fst.base = w3.stack + (size_t)slot * 4u * (unsigned)w3.kp.max_verts;
+            alive = segment<true>(s, h, fst, w3.item_base + slot, 0ull, w3.kp, &lobe, &retry);
         }
 #if SHADE_PROFILE
         { const unsigned long long rm = __ballot(retry); if (lane == 0 && rm) { atomicAdd(&w.kp.ctrl[30], 1u); atomicAdd(&w.kp.ctrl[31], (unsigned)__popcll(rm)); } }
@@ -191,8 +204,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         unsigned base = wg_base[t & 1];
         for (int k = 0; k < wv; k++) base += cnt[k];
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (alive) { PROF_LANES(w.kp.ctrl, 12); }
-        if (alive) emit_ray(w, base + rank, slot, s, qo);
+        SHADE_VIEW(w4);
+        if (alive) { PROF_LANES(w4.kp.ctrl, 12); }
+        if (alive) emit_ray(w4, base + rank, slot, s, qo);
         SHADE_TICK(4);
     }
 #if SHADE_PROFILE
