@@ -31,14 +31,15 @@ constexpr float BROAD_WIDE_SCALE = 1.0000035f;
 struct RayRec {
     float4 a;   // -d' (xyz), od'
     float4 b;   // 2 o (xyz), thr
-    float4 c;   // behind thresholds: hb' > c.x and nq < c.y ; zw unused
+    float4 c;   // behind thresholds: hb' > c.x and nq < c.y;  wide records: z, w = the constants of mf_behind (else +inf, 0)
 };
 
 DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = false) {
     RayRec r;
     const float scale = wide ? BROAD_WIDE_SCALE : BROAD_SCALE, delta = wide ? BROAD_WIDE_DELTA : BROAD_DELTA;
     double px = o.x - T[0], py = o.y - T[1], pz = o.z - T[2];
-    bool far = false;
+    bool far = false, moved = false;
+    double tmove = 0.0;
     if (wide) {
         // The matrix-core test looks at the ray's whole line and has no use for the origin as such, so the origin is
         // moved along the line to the point nearest the scene's centre: |o| and with it the error bounds shrink, and the
@@ -53,8 +54,9 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = fals
         if (!far && dd > 1e-300 && dd < 1e300) {
             const double t = -(px * d.x + py * d.y + pz * d.z) / dd;
             px += t * d.x; py += t * d.y; pz += t * d.z;
+            tmove = t; moved = true;
             const double D2 = px * px + py * py + pz * pz, out = 2.0 * (double)cmax;
-            if (D2 > out * out) { const double k = out / __builtin_sqrt(D2); px *= k; py *= k; pz *= k; }
+            if (D2 > out * out) { const double k = out / __builtin_sqrt(D2); px *= k; py *= k; pz *= k; moved = false; }   // another line: the origin is not on it
         }
     }
     const float ox = (float)px, oy = (float)py, oz = (float)pz;
@@ -70,7 +72,21 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = fals
     const float thr_f = (float)thr - __builtin_fabsf((float)thr) * (4.0f * F32_U) - 1e-30f;
     r.b = make_float4(2.0f * ox, 2.0f * oy, 2.0f * oz, thr_f);
     const float bc = (float)(o2 - (double)E0) - __builtin_fabsf((float)o2) * (4.0f * F32_U);
-    r.c = make_float4(Eh * 1.00001f, bc, 0.0f, 0.0f);
+    // Where the origin went.  The matrix-core test sees hb' = d'.(o' - c) at the MOVED origin o'; at the ray's true origin
+    // o = o' - tmove d it is hb' - tmove (d'.d).  A sphere whose line parameters (-B +- sqrt(disc), B = d.(o - c)) are both
+    // negative lies behind the origin and cannot be hit: B > 0 and B^2 > disc.  The kernel knows disc from above
+    // (thr - s >= disc: the bound that makes the keep test conservative) and B from below:
+    //     hbt = hb_measured - tmv <= d'.(o - c) - Eh,    tmv = tmove (d'.d) rounded up + 2 Eh,
+    // so hbt > 0 and hbt^2 > (s - thr) + mr imply it, mr covering the scale of d' (hb'^2 <= (1 + 7.1e-6) B^2 (1 + 2^-22)), the
+    // rounding of the two fused operations and of s - thr (each below 2^-22 of 4 S^2).  Without a moved origin: never.
+    float tmv = __builtin_inff(), mr = 0.0f;
+    if (wide && moved) {
+        const double tmd = tmove * ((double)fx * d.x + (double)fy * d.y + (double)fz * d.z);
+        const float tf = (float)tmd;
+        tmv = tf + __builtin_fabsf(tf) * (4.0f * F32_U) + 2.0f * Eh + 1e-30f;
+        mr = 6.0e-5f * S * S;
+    }
+    r.c = make_float4(Eh * 1.00001f, bc, tmv, mr);
     // A ray whose float image is not of ordinary size -- NaN, infinite, or so large that the squares above leave the float
     // range (inf - inf is a NaN of either sign, and the keep rule reads a sign) -- gets constants under which every record
     // is kept and none is "behind": s = the record's own fourth word, thr = -inf.  The exact test then sees every solid.
@@ -80,7 +96,7 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = fals
     if (!ordinary) {
         r.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         r.b = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
-        r.c = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+        r.c = make_float4(__builtin_inff(), 0.0f, __builtin_inff(), 0.0f);
     }
     return r;
 }

@@ -31,6 +31,7 @@ struct rt_context {
     bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
     bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
     bool mf_binned = true;                        //   rounds after the camera rays': the binned scan (RT_MFMA_BINNED=0: plain)
+    bool mf_behind = true;                        //   binned scan: groups wholly behind a ray's origin are not listed (RT_MFMA_BEHIND=0: listed)
     // measured on the 4K room with 256 .. 2048 spheres (tools/lattice_probe.py): file order wins up to 256 solids, own order
     // + group records per tile in round 0 from 512, the binned scan in the later rounds from about 1000 (28 groups)
     int mf_min_bounded = 16 * BROAD_GROUP;        //   bounded solids from which the table takes its own order (RT_MFMA_MIN_BOUNDED)
@@ -57,6 +58,7 @@ struct rt_context {
         unsigned* queue[2] = {nullptr, nullptr};
         unsigned* counts = nullptr;
         float4* rec[2] = {nullptr, nullptr};
+        float2* tm = nullptr;
         uint2* cand = nullptr; unsigned* cand_cnt = nullptr;
     } pb[RT_MAX_SUB];
     hipStream_t sub_stream[RT_MAX_SUB] = {};   // overlap mode: the sub-pipelines' streams
@@ -148,7 +150,7 @@ void free_scene(rt_context* h) {
 void free_pipeline(rt_context* h) {
     for (auto& b : h->pb) {
         for (int q = 0; q < 2; q++) { hipFree(b.si[q]); hipFree(b.sd[q]); hipFree(b.queue[q]); hipFree(b.rec[q]); }
-        hipFree(b.stack); hipFree(b.counts); hipFree(b.acc); hipFree(b.cand); hipFree(b.cand_cnt);
+        hipFree(b.stack); hipFree(b.counts); hipFree(b.acc); hipFree(b.cand); hipFree(b.cand_cnt); hipFree(b.tm);
         b = rt_context::PipeBufs();
     }
 }

@@ -133,6 +133,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
+    if (const char* e = getenv("RT_MFMA_BEHIND")) h->mf_behind = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_MIN_BOUNDED")) h->mf_min_bounded = atoi(e);
     if (const char* e = getenv("RT_MFMA_BINNED_MIN")) h->mf_binned_min_groups = atoi(e);
     if (const char* e = getenv("RT_MFMA_LIST")) { const int v = atoi(e); if (v >= 0 && v <= MFB_LIST) h->mf_list_cap = v; }
@@ -591,9 +592,10 @@ static int ensure_pipeline(rt_handle h, rt_context::PipeBufs& b, size_t slots, i
     if (b.slots >= slots && b.verts >= verts && b.iters >= iters) return RT_OK;
     {
         for (int q = 0; q < 2; q++) { hipFree(b.si[q]); hipFree(b.sd[q]); hipFree(b.queue[q]); hipFree(b.rec[q]); }
-        hipFree(b.stack); hipFree(b.counts); hipFree(b.acc); hipFree(b.cand); hipFree(b.cand_cnt);
+        hipFree(b.stack); hipFree(b.counts); hipFree(b.acc); hipFree(b.cand); hipFree(b.cand_cnt); hipFree(b.tm);
         b = rt_context::PipeBufs();
     }
+    HIP_TRY(h, hipMalloc((void**)&b.tm, slots * sizeof(float2)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.si[q], slots * SI_COUNT * sizeof(int)));
     for (int q = 0; q < 2; q++) HIP_TRY(h, hipMalloc((void**)&b.sd[q], slots * SD_COUNT * sizeof(double)));
     HIP_TRY(h, hipMalloc((void**)&b.stack, slots * (size_t)verts * 4 * sizeof(double)));
@@ -642,7 +644,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         w.kp.rgb = d_rgb; w.kp.hit_ids = d_hit_ids;
         for (int q = 0; q < 2; q++) { w.si[q] = b.si[q]; w.sd[q] = b.sd[q]; w.queue[q] = b.queue[q]; w.rec[q] = b.rec[q]; }
         w.stack = b.stack; w.counts = b.counts; w.acc = b.acc;
-        w.cand = b.cand; w.cand_cnt = b.cand_cnt;
+        w.cand = b.cand; w.cand_cnt = b.cand_cnt; w.tm = b.tm;
     }
     unsigned bgrid = 1;
     hipError_t e;
@@ -733,7 +735,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
                     if (it == 0 && h->mf_reordered)
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, true>), dim3(mgrid_cull), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     else if (use_binned)
-                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale, h->mf_list_cap);
+                        hipLaunchKernelGGL(broad_mfma_binned_kernel<MFB_BLOCK>, dim3((unsigned)h->cu_count * 2u), dim3(MFB_BLOCK), binned_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale, h->mf_list_cap, h->mf_behind ? 1 : 0);
                     else
                         hipLaunchKernelGGL((broad_mfma_kernel<MF_BLOCK, false>), dim3(mgrid), dim3(MF_BLOCK), mfma_lds, ss[p], w, (const uint4*)h->d_frags, h->n_groups, mf_win_groups, h->mf_scale);
                     e = hipGetLastError();

@@ -56,6 +56,7 @@ struct WfParams {
     unsigned* queue[2];        // slot ids of the live rays, by queue position
     unsigned* counts;          // counts[i] = live rays entering iteration i
     float4* rec[2];            // ray records by queue position
+    float2* tm;                // by queue position: the constants of the behind test on group records (RayRec::c.z, c.w), rounds after the first
     uint2* cand;               // [WF_CAND_CAP][slots]: entry e of the ray at queue position pos is cand[e * slots + pos]
                                // (neighbouring lanes read neighbouring words): (word index j, keep mask of records 32j..32j+31,
                                // bit 31-k = record 32j+k), only the non-zero words, ascending j
@@ -116,6 +117,7 @@ DEV void emit_ray(const WfParams& w, unsigned pos, unsigned slot, const PathStat
     store_state(w, q, pos, s);
     const RayRec r = broad_setup(s.o, s.d, w.kp.T, w.kp.cmax, w.kp.wide != 0);
     w.rec[0][pos] = r.a; w.rec[1][pos] = r.b;
+    w.tm[pos] = make_float2(r.c.z, r.c.w);
     w.cand_cnt[(size_t)q * w.slots + pos] = 0u;        // broad_kernel's slices add to it
 }
 

@@ -188,6 +188,20 @@ DEV unsigned mf_signs(const f32x16& hb, const f32x16& n) {
     return m;
 }
 
+// mf_signs for group records with the behind test of broad_setup: a group whose bounding sphere lies wholly behind the
+// ray's origin (hbt = hb - tmv > 0 and hbt^2 > (s - thr) + mr; both false for a NaN or an infinite tmv) is not kept
+DEV unsigned mf_signs_behind(const f32x16& hb, const f32x16& n, float tmv, float mr) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float tt = __builtin_fmaf(-hb[i], hb[i], n[i]);
+        const float hbt = hb[i] - tmv;
+        const bool behind = (hbt > 0.0f) & (__builtin_fmaf(hbt, hbt, tt) > mr);
+        m = __builtin_amdgcn_alignbit(m, behind ? 0u : __float_as_uint(tt), 31u);
+    }
+    return m;
+}
+
 constexpr int MF_TILES = 2;                   // ray tiles (of 32 rays) per wave and batch
 
 // For a lane of the lower half: the value of its partner lane (lane + 32).  v_permlane32_swap exchanges the upper half
@@ -370,7 +384,7 @@ constexpr int MFB_LIST = 192;                  // places in a group's ray list; 
 #define MFB_WRITELANE 1     // 0: the ballot words reach their lanes through compare + select
 #endif
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w_arg, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap) {
+__global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w_arg, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap, int behind) {
     extern __shared__ uint4 mf_lds[];
     const WfParams& w = w_arg;
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
@@ -411,6 +425,8 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const WfParams& wa = w_arg;
 #endif
             const float4 ra = valid ? wa.rec[0][pos] : none, rb = valid ? wa.rec[1][pos] : none;
+            float tmv = __builtin_inff(), mr = 0.0f;          // the behind test's constants, in the table's scaled lengths
+            if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
             const bool ordinary = mf_ordinary(ra, rb, scale);
             const RayFrag rf = mf_ray_frag(ra, rb, scale, h, ordinary);
             F16Pack p0, p1;
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             {
                 f32x16 hb, nn;
                 mf_products(gfr[gn * MF_GROUP_WORDS + lane], rf, hb, nn);
-                const unsigned mine = mf_signs(hb, nn);
+                const unsigned mine = mf_signs_behind(hb, nn, tmv, mr);
                 const unsigned full = (mine << 16) | mf_from_upper_half(mine);
                 gm = own ? full : 0u;
             }

@@ -219,6 +219,26 @@ def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
     assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
 
 
+def test_groups_behind_the_origin_are_dropped_not_hits(renderer, monkeypatch):
+    """The binned scan does not list a ray for a group whose bounding sphere lies wholly behind the ray's origin (both
+    line parameters negative, decided from a lower bound of d.(o - c) and an upper bound of the discriminant).  It must
+    compute fewer products and keep fewer candidates than with RT_MFMA_BEHIND=0, and leave every output bit alone."""
+    _, sc = synth.make("c3", width=960)
+    renderer.upload(sc)
+    a = renderer.render(want_hits=True)
+    ta = renderer.timing()
+    monkeypatch.setenv("RT_MFMA_BEHIND", "0")
+    other = api.Renderer(0)
+    try:
+        other.upload(sc)
+        b = other.render(want_hits=True)
+        tb = other.timing()
+    finally:
+        other.close()
+    assert ta["broad_tiles"] < 0.97 * tb["broad_tiles"] and ta["candidates"] < tb["candidates"], (ta, tb)
+    assert a["rays"] == b["rays"] and np.array_equal(a["hits"], b["hits"]) and bits_equal(a["rgb"], b["rgb"]).all()
+
+
 @pytest.mark.parametrize("env", [{"RT_MFMA_LIST": "0"}, {"RT_MFMA_LIST": "24"}, {"RT_MFMA_BINNED": "0"}])
 def test_binned_scan_variants_do_not_change_bits(renderer, monkeypatch, env):
     """The scan of the later rounds lists every group's rays and computes only listed (group, rays) products.  A group
