@@ -665,7 +665,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     const size_t mfma_lds = (size_t)(mf_win_groups + (mf_win_groups + BROAD_GROUP - 1) / BROAD_GROUP) * MF_GROUP_BYTES;
     // the binned scan: 1024 threads, two workgroups per CU (LDS: the window, 512 rays' fragments, the groups' ray lists)
     constexpr int MFB_BLOCK = 1024, MFB_RAYS = MFB_BLOCK / 2;
-    const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)MFB_RAYS * 64 + (size_t)MFB_GROUPS * MFB_LIST * 2 +
+    const size_t binned_lds = (size_t)(mf_win_groups + 1) * MF_GROUP_BYTES + (size_t)(MFB_RAYS + 1) * 64 + (size_t)MFB_GROUPS * MFB_LIST * 2 +
                               (size_t)MFB_RAYS * 4 + 2 * MFB_GROUPS * 4;
     const bool use_binned = h->mf_reordered && h->mf_binned && h->n_groups >= h->mf_binned_min_groups;
     unsigned mgrid = 1, mgrid_cull = 1;

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
     // ray lists, the rays' list lengths, the groups' list lengths (two copies, by pass parity)
     uint4* const gfr = mf_lds;
     uint4* const rayf = gfr + win_words;
-    unsigned short* const lists = (unsigned short*)(rayf + RAYS * 4);
+    unsigned short* const lists = (unsigned short*)(rayf + (RAYS + 1) * 4);     // fragment RAYS: zeros, for the places of an item no ray fills
     unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * MFB_LIST);
     unsigned* const gcount2 = rcnt + RAYS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
         __syncthreads();                                       // the previous window's last items are done
         for (int i = threadIdx.x; i < (gn + 1) * MF_GROUP_WORDS; i += BLOCK) gfr[i] = frags[(size_t)win * win_words + i];
         if (threadIdx.x < 2 * MFB_GROUPS) gcount2[threadIdx.x] = 0u;
+        if (threadIdx.x < 4) rayf[RAYS * 4 + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x, pass++) {
             unsigned* const gcount = gcount2 + (pass & 1u) * MFB_GROUPS;
@@ -509,11 +510,10 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 const unsigned n_in = all_rays ? 32u : cgg - c * 32u;
                 const bool have = (unsigned)r < n_in;
                 unsigned id = c * 32u + (unsigned)r;
-                if (!all_rays) id = have ? (unsigned)lists[g * MFB_LIST + id] : 0u;
+                if (!all_rays) id = have ? (unsigned)lists[g * MFB_LIST + id] : (unsigned)RAYS;
                 RayFrag q;
                 F16Pack a0, a1;
                 a0.u = rayf[id * 4 + h * 2 + 0]; a1.u = rayf[id * 4 + h * 2 + 1];
-                if (!have) { a0.u = make_uint4(0u, 0u, 0u, 0u); a1.u = a0.u; }
                 q.q0 = a0.v; q.q1 = a1.v;
                 f32x16 hb, nn;
                 mf_products(gfr[g * MF_GROUP_WORDS + lane], q, hb, nn);
