@@ -171,6 +171,24 @@ DEV RayFrag mf_ray_frag(const float4 ra, const float4 rb, float s, int h, bool o
     return f;
 }
 
+// mf_ray_frag for both lane halves at once: out[0..1] = (q0, q1) of half 0, out[2..3] = those of half 1
+DEV void mf_ray_frag_both(const float4 ra, const float4 rb, float s, bool ordinary, uint4* out) {
+    const float od = ra.w * s, n0 = -rb.x * s, n1 = -rb.y * s, n2 = -rb.z * s;
+    float thr = rb.w * s * s;
+    if (thr < 0.0f) thr = __builtin_fmaf(thr, 0x1p-20f, thr);
+    const unsigned A01 = mf_pk(ra.x, ra.y), A2o = mf_pk(ra.z, od), N01 = mf_pk(n0, n1), N2t = mf_pk(n2, thr);
+    const unsigned a01 = mf_pk(ra.x - mf_lo(A01), ra.y - mf_hi(A01)), a2o = mf_pk(ra.z - mf_lo(A2o), od - mf_hi(A2o));
+    const unsigned m01 = mf_pk(n0 - mf_lo(N01), n1 - mf_hi(N01)), m2t = mf_pk(n2 - mf_lo(N2t), thr - mf_hi(N2t));
+    const unsigned al2 = a2o & 0xffffu, nl2 = (m2t & 0xffffu) | (F16_MINUS_ONE << 16);
+    out[0] = make_uint4(A01, A2o, A01, (A2o & 0xffffu) | (a2o & 0xffff0000u));
+    out[1] = make_uint4(N01, N2t, N01, (N2t & 0xffffu) | (m2t & 0xffff0000u));
+    out[2] = make_uint4(a01, al2, a01, al2);
+    out[3] = make_uint4(m01, nl2, m01, nl2);
+    if (!ordinary) { out[0] = make_uint4(0u, 0u, 0u, 0u); out[1] = out[0]; out[2] = out[0]; out[3] = out[0]; }
+}
+// For every lane: the value of the lane of the LOWER half that sits 32 below it (lanes of the lower half get their own)
+DEV unsigned mf_from_lower_half(unsigned v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[0]; }
+
 // the two products of one tile (32 rays) with one group (32 records): hb and N = thr - nq, 16 values each per lane
 DEV void mf_products(const uint4 fu, const RayFrag& rf, f32x16& hb, f32x16& n) {
     F16Pack f;
@@ -383,11 +401,15 @@ constexpr int MFB_LIST = 192;                  // places in a group's ray list; 
 #ifndef MFB_WRITELANE
 #define MFB_WRITELANE 1     // 0: the ballot words reach their lanes through compare + select
 #endif
+#ifndef MFB_WIDE
+#define MFB_WIDE 1          // 0: every wave prepares 32 rays, both lane halves building the same ray's pieces (scan +0.11 ms per C3 frame)
+#endif
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfParams w_arg, const uint4* __restrict__ frags, int n_groups, int win_groups, float scale, int list_cap, int behind) {
     extern __shared__ uint4 mf_lds[];
     const WfParams& w = w_arg;
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
+    constexpr int NBUILD = NW / 2;                         // MFB_WIDE: the waves that prepare a pass's rays, 64 each
     constexpr unsigned SKIP = 0xffffffffu;
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
@@ -415,6 +437,94 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
         __syncthreads();
         for (unsigned batch = blockIdx.x; batch < nbatches; batch += gridDim.x, pass++) {
             unsigned* const gcount = gcount2 + (pass & 1u) * MFB_GROUPS;
+#if MFB_WIDE
+            // ---- the first half of the waves: 64 rays each -- a lane builds both lane halves' fragments of its ray (the
+            // pieces are the same work for both), the group records are asked in two tiles of 32 rays whose operands come
+            // back out of LDS, one 64-bit ballot per group serves all 64 rays, and the lanes k and k + 32 enter the wave's
+            // lower and upper 32 rays of group k in its list
+            const unsigned local = (unsigned)(wv * 64 + lane);
+            const unsigned pos = batch * RAYS + local;
+            const bool builder = wv < NBUILD;
+            const bool valid = builder && pos < count;
+            if (builder) {
+                const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+#if MFB_KARG
+                const WfParams& wa = karg_view();
+#else
+                const WfParams& wa = w_arg;
+#endif
+                const float4 ra = valid ? wa.rec[0][pos] : none, rb = valid ? wa.rec[1][pos] : none;
+                float tmv = __builtin_inff(), mr = 0.0f;      // the behind test's constants, in the table's scaled lengths
+                if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
+                const bool ordinary = mf_ordinary(ra, rb, scale);
+                uint4 fr4[4];
+                mf_ray_frag_both(ra, rb, scale, ordinary, fr4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rayf[local * 4 + k] = fr4[k];
+                const bool own = valid && ordinary;
+                {
+                    unsigned n0 = SKIP;                        // no ray here, or one whose list is marked as overflowed
+                    if (valid && !ordinary) { if (win == 0) cand_cnt[pos] = WF_OVERFLOW; }
+                    else if (valid) {
+                        n0 = 0u;
+                        if (win > 0) { n0 = cand_cnt[pos]; if (n0 > (unsigned)WF_CAND_CAP) n0 = (unsigned)WF_CAND_CAP + 1u; }
+                    }
+                    rcnt[local] = n0;
+                }
+                // the constants of the tile's rays: tile 0's sit in the lower lane half, tile 1's in the upper
+                const unsigned tmv_u = __float_as_uint(tmv), mr_u = __float_as_uint(mr);
+                const float tmv0 = __uint_as_float(mf_from_lower_half(tmv_u)), tmv1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(tmv_u, tmv_u, false, false)[1]);
+                const float mr0 = __uint_as_float(mf_from_lower_half(mr_u)), mr1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(mr_u, mr_u, false, false)[1]);
+                const uint4 gf = gfr[gn * MF_GROUP_WORDS + lane];
+                unsigned full0, full1;
+                {
+                    RayFrag q;
+                    F16Pack a0, a1;
+                    const unsigned id = (unsigned)(wv * 64 + r);
+                    a0.u = rayf[id * 4 + h * 2 + 0]; a1.u = rayf[id * 4 + h * 2 + 1];
+                    q.q0 = a0.v; q.q1 = a1.v;
+                    f32x16 hb, nn;
+                    mf_products(gf, q, hb, nn);
+                    const unsigned mine = mf_signs_behind(hb, nn, tmv0, mr0);
+                    full0 = (mine << 16) | mf_from_upper_half(mine);          // lane r < 32: the word of ray r
+                }
+                {
+                    RayFrag q;
+                    F16Pack a0, a1;
+                    const unsigned id = (unsigned)(wv * 64 + 32 + r);
+                    a0.u = rayf[id * 4 + h * 2 + 0]; a1.u = rayf[id * 4 + h * 2 + 1];
+                    q.q0 = a0.v; q.q1 = a1.v;
+                    f32x16 hb, nn;
+                    mf_products(gf, q, hb, nn);
+                    const unsigned mine = mf_signs_behind(hb, nn, tmv1, mr1);
+                    full1 = (mine << 16) | mf_from_upper_half(mine);          // lane r < 32: the word of ray 32 + r
+                }
+                const unsigned up = mf_from_lower_half(full1);                // lane 32 + r: the word of ray 32 + r
+                const unsigned gm = own ? (h == 0 ? full0 : up) : 0u;
+                // group k's rays of this wave as a 64-bit ballot; its lower word goes to lane k, its upper word to lane k + 32
+                unsigned bw = 0;
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const unsigned long long b = __ballot((gm & (0x80000000u >> k)) != 0u);
+                    // (wait states: see the comment at the narrow form below)
+                    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                                 : "+v"(bw) : "s"((unsigned)b), "s"((unsigned)(b >> 32)), "i"(k), "i"(k + 32));
+                }
+                // lanes k and k + 32 share one reservation in group k's list: the lower lane asks for both
+                const unsigned cnt = (unsigned)__popc(bw);
+                const unsigned cnt_hi = mf_from_upper_half(cnt);
+                unsigned base = 0u;
+                if (h == 0 && cnt + cnt_hi != 0u) base = atomicAdd(&gcount[lane], cnt + cnt_hi);
+                const unsigned base_lo = mf_from_lower_half(base), cnt_lo = mf_from_lower_half(cnt);
+                unsigned place = h == 0 ? base : base_lo + cnt_lo;
+                unsigned short* const lk = lists + r * MFB_LIST;
+                while (bw != 0u && place < (unsigned)list_cap) {
+                    const int rr = __builtin_ctz(bw);
+                    bw &= bw - 1u;
+                    lk[place++] = (unsigned short)(wv * 64 + h * 32 + rr);
+                }
+            }
+#else
             // ---- every wave: its 32 rays' fragments into LDS, their group masks, the groups' lists
             const unsigned local = (unsigned)(wv * 32 + r);
             const unsigned pos = batch * RAYS + local;
@@ -479,6 +589,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                     lk[place++] = (unsigned short)(wv * 32 + rr);
                 }
             }
+#endif
             __syncthreads();                                   // the lists are complete
             // ---- items (group, 32 rays): lane g < 32 holds group g's range of item numbers.  A group whose list did
             // not hold all its rays takes the pass's rays as they come (NW items), no list.
@@ -493,7 +604,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const unsigned start = incl - chunks;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
             if (threadIdx.x < MFB_GROUPS) gcount2[((pass & 1u) ^ 1u) * MFB_GROUPS + threadIdx.x] = 0u;     // the next pass's counters
-            tiles_done += 1u + (total > (unsigned)wv ? (total - (unsigned)wv + NW - 1u) / NW : 0u);      // group records + this wave's items
+            tiles_done += (MFB_WIDE ? (wv < NBUILD ? 2u : 0u) : 1u) + (total > (unsigned)wv ? (total - (unsigned)wv + NW - 1u) / NW : 0u);      // group records + this wave's items
 #if MFB_KARG
             const WfParams& wc = karg_view();
 #else
@@ -527,7 +638,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             }
             __syncthreads();                                   // every item is done
             // ---- the rays' list lengths, by the lanes that own the rays (they set the next pass's start values next)
-            if (h == 0) {
+            if (MFB_WIDE ? valid : h == 0) {
                 const unsigned n1 = rcnt[local];
                 if (n1 != SKIP) cand_cnt[pos] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
             }
