@@ -115,8 +115,9 @@ class FrameGatherer:
         if self.rank != 0:
             return None
         if self.world == 1:
-            # one rank owns every tile, in order: its buffer is the frame
-            self.frame.copy_(self._sent[: self.h])
+            # one rank owns every tile, in order: its buffer IS the frame (a view of the send buffer just filled; the
+            # next step fills the other one)
+            return self._sent[: self.h]
         else:
             torch.index_select(self._recv_all[self._recv_sent].view(self.world * self.pad_rows, -1), 0, self.src_row, out=self.frame)
         return self.frame
