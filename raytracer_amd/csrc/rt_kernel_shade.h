@@ -139,6 +139,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         LobeCtx lobe;
         lobe.n = dmk(0, 0, 0); lobe.cost = lobe.sint = lobe.inv_exp = 0.0; lobe.flat = false;
         PathState s;
+        s.rng = 0u; s.d = dmk(0, 0, 0); s.pv_n = dmk(0, 0, 0);      // what lobe_retry_pool reads of every lane, live or not
         unsigned slot = 0;
         SHADE_TICK(0);
         // the closest hit needs the ray only; the rest of the path state is loaded after it (fewer live registers)
