@@ -850,7 +850,7 @@ int rt_finish(rt_handle h, uint64_t* rays) {
             hipMemcpy(la, h->d_ctrl + 64, sizeof(la), hipMemcpyDeviceToHost);
             static const char* names[24] = {"candidate test", "always tests", "segment", "sphere normal", "plane material", "factor", "factor pow",
                                             "light product step", "dead end", "reflect", "refract", "end_path", "emit", "heavy ray", "retry pass", "state load",
-                                            "list scan step", "", "", "", "", "", "", ""};
+                                            "list scan step", "walk: ray", "walk: step", "walk: first item", "walk: further item", "", "", ""};
             for (int k = 0; k < 24; k++)
                 if (la[2 * k + 1]) fprintf(stderr, "  lanes %-20s entries %10llu  mean active %5.1f of 64\n", names[k], la[2 * k + 1], (double)la[2 * k] / (double)la[2 * k + 1]);
         }

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
     unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
     const float inf = __builtin_inff();
     for (unsigned pos = blockIdx.x * blockDim.x + threadIdx.x; pos < count; pos += stride) {
+        PROF_LANES(w.kp.ctrl, 17);
         const float4 ra = w.rec[0][pos], rb = w.rec[1][pos];
         uint2* out = w.cand + pos;
         const size_t cstride = w.slots;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
         for (int it = 0; it < max_steps; it++) {
             // the next cell: through the nearest of the three next boundaries; its record is requested before the
             // current cell's solids are tested
+            PROF_LANES(w.kp.ctrl, 18);
             const int ax = (tmax[0] <= tmax[1] && tmax[0] <= tmax[2]) ? 0 : (tmax[1] <= tmax[2] ? 1 : 2);
             const float texit = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
             const int st = ax == 0 ? step[0] : (ax == 1 ? step[1] : step[2]);
@@ -159,8 +161,10 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
             nsteps++; ntests += cnt;
 #endif
             if (cnt != 0u) {
+                PROF_LANES(w.kp.ctrl, 19);
                 test_item(make_float4(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w)), c1.x, __uint_as_float(c1.y));
                 for (unsigned i = 0; i + 1u < cnt; i++) {
+                    PROF_LANES(w.kp.ctrl, 20);
                     const uint2 aux = g.item_aux[c1.w + i];
                     test_item(g.item_rec[c1.w + i], aux.x, __uint_as_float(aux.y));
                 }
