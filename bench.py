@@ -238,6 +238,7 @@ def main():
     frame_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # all kernels of one frame on this GPU
     head_hash = frame_hash(frame)
     source_used = int(ren.timing()["accel_used"])
+    sub_pipelines = int(ren.timing()["sub_pipelines"])      # parts of this rank's pixels that ran side by side in the timed frames
     source_name = {api.ACCEL_SCAN: "scan", api.ACCEL_WALK: "grid_walk"}[source_used]
 
     # ---- per-kernel times, outside the timed region: a few more frames with HIP events around every scan (or walk) and
@@ -385,7 +386,7 @@ def main():
             "vs_baseline": None, "dtype": "f64 exact phase + " + ("f16x2 MFMA / f32 candidate filter" if on_mfma else "f32 candidate filter"), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {cnt['spheres']} spheres + {cnt['planes']} planes + {cnt['faces']} faces, "
                                    f"depth {sc.header['max_ray_depth']}, {sc.spp} spp",
-                       "rays_per_frame": rays_frame, "tile_rows": args.tile_rows, "candidate_source": source_name,
+                       "rays_per_frame": rays_frame, "tile_rows": args.tile_rows, "candidate_source": source_name, "sub_pipelines": sub_pipelines,
                        "frame_sha256_16": head_hash,
                        "flop_credit": "algorithmic figures: 19 per ray-sphere, 12 per ray-plane, 18 + 7 per vertex per ray-face (46 for a quad)",
                        "partition": f"cyclic row tiles over {world} GPU(s), packed 8-bit rows gathered to rank 0",

@@ -105,6 +105,8 @@ typedef struct {
     uint64_t accel_used;    /* last render: RT_ACCEL_SCAN or RT_ACCEL_WALK */
     double shade_ms;        /* last render: sum over its shade_kernel launches (exact closest hit + one path segment   */
                             /* per ray), measured like broad_ms only while RT_OPT_TIMING_DETAIL is on (else 0)          */
+    uint64_t sub_pipelines; /* last render: parts of the rank's pixels that went through the pipeline side by side on   */
+                            /* streams of their own (RT_OPT_OVERLAP above RT_OVERLAP_MIN_PIXELS pixels, else 1)          */
 } rt_timing;
 
 /* options for rt_set_option */
@@ -137,7 +139,7 @@ enum {
  * set the same values as rt_set_option): RT_MODE, RT_BLOCK, RT_BROAD_BLOCK, RT_WG_PER_CU, RT_CHUNK_RECORDS, RT_OVERLAP,
  * RT_ACCEL; RT_ACCEL_MIN_BOUNDED, RT_GRID_DENSITY (grid walk); RT_BROAD_MFMA, RT_MFMA_CULL, RT_MFMA_MIN_BOUNDED,
  * RT_MFMA_BINNED, RT_MFMA_BINNED_MIN, RT_MFMA_LIST, RT_MFMA_BEHIND (matrix-core scan); RT_NO_BOX; and, at every render,
- * RT_SHADE_GRID.  rt_multi_create also reads RT_MULTI_LOOPBACK and RT_MULTI_FORCE_RCCL. */
+ * RT_SHADE_GRID; RT_OVERLAP_MIN_PIXELS (pixels of a render from which RT_OPT_OVERLAP applies).  rt_multi_create also reads RT_MULTI_LOOPBACK and RT_MULTI_FORCE_RCCL. */
 int rt_create(rt_handle* out, int device);
 
 /* Free device buffers and the context.  Replaces main.cpp:328-331. */

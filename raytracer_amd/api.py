@@ -45,7 +45,8 @@ class RtError(RuntimeError):
 class RtTiming(C.Structure):
     _fields_ = [("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("broad_ms", C.c_double), ("total_ms", C.c_double),
                 ("rays", C.c_uint64), ("candidates", C.c_uint64), ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
-                ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64), ("overflow_rays", C.c_uint64), ("broad_tiles", C.c_uint64), ("broad_records", C.c_uint64), ("accel_used", C.c_uint64), ("shade_ms", C.c_double)]
+                ("face_tests", C.c_uint64), ("face_vert_tests", C.c_uint64), ("overflow_rays", C.c_uint64), ("broad_tiles", C.c_uint64), ("broad_records", C.c_uint64), ("accel_used", C.c_uint64), ("shade_ms", C.c_double),
+                ("sub_pipelines", C.c_uint64)]
 
 
 _lib = None

@@ -87,6 +87,8 @@ struct rt_context {
     int chunk_records = 8192;  // LDS window in records (16 bytes each)
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    uint64_t overlap_min_pixels = 3ull << 20;   // ... for renders of at least this many pixels (RT_OVERLAP_MIN_PIXELS), see render_pipeline
+    int last_sub = 1;          // sub-pipelines of the last render
     int broad_mfma = 1;        // 1: the broad phase runs on the matrix cores (broad_mfma_kernel), 0: on the vector ALU (broad_kernel)
     bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
     int accel = RT_ACCEL_AUTO; // pipeline: candidate lists from the scan of every record (0), from the grid walk (1), or whichever is

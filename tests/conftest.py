@@ -38,3 +38,6 @@ def _scan_unless_a_test_says_otherwise(monkeypatch):
     by rt_create) unless a test sets the option: the tests name the source they look at.  The library's own per-scene
     choice (RT_ACCEL_AUTO) has a test of its own, which removes the variable."""
     monkeypatch.setenv("RT_ACCEL", "0")
+    # the small frames of the tests go through two sub-pipelines on two streams, as the large ones of the product do
+    # (left to the library that starts at 3 M pixels; its own choice has a test of its own)
+    monkeypatch.setenv("RT_OVERLAP_MIN_PIXELS", "65536")

@@ -129,3 +129,28 @@ def test_library_picks_the_candidate_source_per_scene(monkeypatch):
             assert np.array_equal(auto["rgb"].view(np.uint64), other["rgb"].view(np.uint64))
     finally:
         r.close()
+
+
+def test_library_splits_large_renders_only(monkeypatch):
+    """RT_OPT_OVERLAP = 2 (the default) applies from RT_OVERLAP_MIN_PIXELS pixels on (3 M unless set): a 1920 x 1080 frame
+    goes through the pipeline in one piece, a 2560 x 1440 frame in two halves on two streams; rt_timing.sub_pipelines says
+    which, and the frame is the same either way."""
+    monkeypatch.delenv("RT_OVERLAP_MIN_PIXELS", raising=False)
+    own = api.Renderer(0)
+    monkeypatch.setenv("RT_OVERLAP_MIN_PIXELS", "0")
+    split = api.Renderer(0)
+    try:
+        for width, want in ((1920, 1), (2560, 2)):
+            _, sc = synth.make("c2", width=width)
+            own.upload(sc); split.upload(sc)
+            a = own.render()
+            assert own.timing()["sub_pipelines"] == want, width
+            b = split.render()
+            assert split.timing()["sub_pipelines"] == 2
+            assert a["rays"] == b["rays"]
+            assert np.array_equal(a["rgb"].view(np.uint64), b["rgb"].view(np.uint64))
+        own.set_option(api.OPT_OVERLAP, 1)
+        own.render()
+        assert own.timing()["sub_pipelines"] == 1
+    finally:
+        own.close(); split.close()
