@@ -74,14 +74,22 @@ DEV const WfParams& karg_view() {
     return *(const WfParams*)p;
 }
 
-// the ray itself (o, d) was read before the closest-hit search and is passed in
-DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, d3 ro, d3 rd, PathState& s) {
+// the four state words of the ray at queue position pos
+struct StateWords { int rng, sample, pack, pv_mat; };
+DEV StateWords load_state_words(const WfParams& w, int q, unsigned pos) {
     const size_t n = w.slots;
     const int* si = w.si[q] + pos;
-    s.rng = (unsigned)si[SI_RNG * n];
-    s.sample = si[SI_SAMPLE * n];
-    const int pk = si[SI_PACK * n];
-    s.pv_mat = si[SI_PVMAT * n];
+    StateWords v;
+    v.rng = si[SI_RNG * n]; v.sample = si[SI_SAMPLE * n]; v.pack = si[SI_PACK * n]; v.pv_mat = si[SI_PVMAT * n];
+    return v;
+}
+// the ray itself (o, d) and the state words were read before the closest-hit search and are passed in
+DEV void load_state(const WfParams& w, int q, unsigned pos, unsigned slot, d3 ro, d3 rd, const StateWords& sw, PathState& s) {
+    const size_t n = w.slots;
+    s.rng = (unsigned)sw.rng;
+    s.sample = sw.sample;
+    const int pk = sw.pack;
+    s.pv_mat = sw.pv_mat;
     s.remaining = (int)(signed char)(pk & 0xff);
     s.nverts = (pk >> 8) & 0xff;
     s.flags = (pk >> 16) & 0xff;

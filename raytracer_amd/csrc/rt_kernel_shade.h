@@ -2,6 +2,16 @@
 // A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
 #pragma once
 
+#ifndef SHADE_EARLY_HP
+#define SHADE_EARLY_HP 1
+#endif
+#ifndef SHADE_EARLY_PVM
+#define SHADE_EARLY_PVM 0
+#endif
+#ifndef SHADE_REC_AHEAD
+#define SHADE_REC_AHEAD 1
+#endif
+
 namespace {
 
 // Closest hit of the ray queued at `pos` (get_intersection, main.cpp:34-43): the always-tested solids (table `alw`, LDS)
@@ -47,6 +57,50 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
 #if DIAG_TWICE_CAND
         for (int rep = 0; rep < 2; rep++) {
         if (rep) { if (n > 0u) cur = cl[0]; if (n > 1u) nxt = cl[cstride]; }
+#endif
+#if SHADE_REC_AHEAD
+        if (PLACES) {
+            // The candidates as one stream of places, each one's record requested while the one before it is tested: a wave's
+            // lanes hold a few candidates each and a dependent read of the table costs a microsecond under load, so the
+            // reads, not the tests, set the length of this loop.
+            unsigned e = 0, m = 0, word = 0;
+            auto next_place = [&]() -> int {
+                while (m == 0u) {
+                    if (e >= n) return -1;
+                    word = cur.x; m = cur.y;
+                    cur = nxt;
+                    if (e + 2u < n) nxt = cl[(e + 2u) * cstride];
+                    e++;
+                    ncand_total += (unsigned)__popc(m);
+                }
+                const int k = __clz((int)m);
+                m &= ~(0x80000000u >> k);
+                return (int)word * BROAD_GROUP + k;
+            };
+            // records in flight: the one under test and SHADE_REC_AHEAD more (one: a second costs 12 spilled registers and
+            // 0.1 ms, touching its cache line a step earlier instead 0.03 ms)
+            struct Rec { int place; double2 a01, a2r; int idx; };
+            auto fetch = [&]() -> Rec {
+                Rec r;
+                r.place = next_place();
+                r.a01 = make_double2(0.0, 0.0); r.a2r = make_double2(0.0, 0.0); r.idx = 0;
+                if (r.place >= 0) { const double* c = w.kp.mf_cand + 4 * (size_t)r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)w.kp.mf_perm[r.place]; }
+                return r;
+            };
+            Rec q[SHADE_REC_AHEAD + 1];
+#pragma unroll
+            for (int k = 0; k <= SHADE_REC_AHEAD; k++) q[k] = fetch();
+            while (q[0].place >= 0) {
+                PROF_LANES(w.kp.ctrl, 0);
+                const Rec t = q[0];
+#pragma unroll
+                for (int k = 0; k < SHADE_REC_AHEAD; k++) q[k] = q[k + 1];
+                q[SHADE_REC_AHEAD] = fetch();
+                // (a place that holds no solid reads as a NaN radius and an index past the list)
+                if ((t.a2r.y == t.a2r.y) || t.idx < w.kp.n_prims)
+                    consider(narrow_point_from(t.idx, dmk(t.a01.x, t.a01.y, t.a2r.x), t.a2r.y, o, d, w.kp.prims, w.kp.verts), t.idx, o, h);
+            }
+        } else
 #endif
         for (unsigned e = 0; e < n; e++) {
             const uint2 ent = cur;
@@ -165,6 +219,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         SHADE_VIEW(w3);
+        PvMaterial pvm;
+        pvm.c01 = pvm.c2s0 = pvm.s12 = make_double2(0.0, 0.0); pvm.sexp = 1.0;
+        HitPrim hp;
+        hp.ids = make_int4(0, 0, 0, 0); hp.a01 = hp.a2r = hp.n01 = hp.n2p = make_double2(0.0, 0.0);
         if (live) {
             if (FIRST) {
                 map_item_to_pixel(w3.item_base + slot, w3.kp, s.px, s.py);
@@ -174,12 +232,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
                 s.acc_mem = w3.acc + slot; s.acc_stride = w3.slots;
             } else {
                 PROF_LANES(w3.kp.ctrl, 15);
+                // requested side by side: the hit solid's record (what the search knows suffices for that) and the path
+                // state; then, side by side again, the two materials they name (the hit's inside segment())
+#if SHADE_EARLY_HP
+                if (h.idx >= 0) hp = load_hit_prim(w3.kp, h.idx);
+#endif
                 slot = w3.queue[qi][pos];
-                load_state(w3, qi, pos, slot, ro, rd, s);
+                const StateWords sw = load_state_words(w3, qi, pos);
+                load_state(w3, qi, pos, slot, ro, rd, sw, s);
+#if SHADE_EARLY_PVM
+                if (s.nverts > 0) pvm = load_pv_material(w3.kp, s.pv_mat, s.flags);
+#endif
             }
             nrays++;
             FactorStackV fst; fst.base = w3.stack + (size_t)slot * 4u * (unsigned)w3.kp.max_verts;
-            alive = segment<true>(s, h, fst, w3.item_base + slot, 0ull, w3.kp, &lobe, &retry);
+            alive = segment<true>(s, h, fst, w3.item_base + slot, 0ull, w3.kp, &lobe, &retry, (FIRST || !SHADE_EARLY_PVM) ? nullptr : &pvm, (FIRST || !SHADE_EARLY_HP) ? nullptr : &hp);
         }
 #if SHADE_PROFILE
         { const unsigned long long rm = __ballot(retry); if (lane == 0 && rm) { atomicAdd(&w.kp.ctrl[30], 1u); atomicAdd(&w.kp.ctrl[31], (unsigned)__popcll(rm)); } }

@@ -2,6 +2,10 @@
 // A section of librt_hip.so's single translation unit: rt_device.hip includes the sections in dependency order.
 #pragma once
 
+#ifndef SEGMENT_EARLY_LOADS
+#define SEGMENT_EARLY_LOADS 1
+#endif
+
 namespace {
 
 // ---- per-path state and one segment of add_to_path -------------------------------------------
@@ -104,32 +108,82 @@ DEV bool end_path(PathState& s, double c0, double c1, double c2, unsigned item, 
 // POOL: the caller draws the further samples of a rejected glossy sample (lobe_retry_pool) -- *retry is then set and *lobe
 // filled; the state already holds everything else of the new ray (s.pv_n is the surface normal the samples are tested
 // against).  Without POOL the rejection loop runs inside.
+// The words of the previous vertex's material that its throughput factor takes (Path::trace, geometry.cpp:190-213), read
+// by the caller as soon as the path state names that material -- beside the other reads that follow the closest-hit
+// search instead of behind them (segment() reads them itself when it is handed none).
+struct PvMaterial { double2 c01, c2s0, s12; double sexp; };
+DEV PvMaterial load_pv_material(const KParams& kp, int pv_mat, int flags) {
+    const MatD* pm = kp.mats + pv_mat;
+    const double* cs = (flags & FL_PV_REFLECT) ? pm->diff : pm->rdiff;       // (diffuse, specular) or the refraction pair
+    PvMaterial v;
+    v.c01 = ld2(cs); v.c2s0 = ld2(cs + 2); v.s12 = ld2(cs + 4);
+    v.sexp = pm->sexp;
+    return v;
+}
+
+// the hit solid's record, whole (96 bytes in five reads)
+struct HitPrim { int4 ids; double2 a01, a2r, n01, n2p; };
+DEV HitPrim load_hit_prim(const KParams& kp, int idx) {
+    const PrimD* pi = kp.prims + idx;
+    HitPrim v;
+    v.ids = ldi4(&pi->kind);                           // kind, mat0, mat1, voff
+    v.a01 = ld2(pi->a); v.a2r = ld2(pi->a + 2);
+    v.n01 = ld2(pi->n); v.n2p = ld2(pi->n + 2);
+    return v;
+}
+
 template <bool POOL, class FStack>
 DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, unsigned long long item_rays,
-                 const KParams& kp, LobeCtx* lobe = nullptr, bool* retry = nullptr) {
+                 const KParams& kp, LobeCtx* lobe = nullptr, bool* retry = nullptr, const PvMaterial* pvm = nullptr,
+                 const HitPrim* hpre = nullptr) {
     if (s.flags & FL_FIRST_SEG) {
         if (kp.hit_ids) kp.hit_ids[(size_t)s.out_index * kp.spp + s.sample] = h.idx;
         s.flags &= ~FL_FIRST_SEG;
     }
     PROF_LANES(kp.ctrl, 2);
     if (h.idx < 0) return end_path(s, 0.0, 0.0, 0.0, item, item_rays, kp);           // main.cpp:179-182
+    // The solid's record is requested whole, before its kind is known, and a material's words in one go: a read that waits
+    // for another read's result costs a microsecond here, and the kernel's time is made of such chains (kind -> centre or
+    // normal -> material -> exponent were four of them, now two).
+#if SEGMENT_EARLY_LOADS
+    const HitPrim hp = hpre ? *hpre : load_hit_prim(kp, h.idx);
+    const int4 ids = hp.ids;
+    const double2 a01 = hp.a01, a2r = hp.a2r, n01 = hp.n01, n2p = hp.n2p;
+#else
     const PrimD* pi = kp.prims + h.idx;
     const int4 ids = ldi4(&pi->kind);                  // kind, mat0, mat1, voff
+#endif
     const int kind = ids.x;
     d3 normal;
     int mi = ids.y;
     if (kind == RT_KIND_SPHERE) {
         PROF_LANES(kp.ctrl, 3);
+#if !SEGMENT_EARLY_LOADS
         const double2 a01 = ld2(pi->a), a2r = ld2(pi->a + 2);
+#endif
         normal = dnorm(dsub(h.p, dmk(a01.x, a01.y, a2r.x)));
     } else {
+#if !SEGMENT_EARLY_LOADS
         const double2 n01 = ld2(pi->n), n2p = ld2(pi->n + 2);
+#endif
         normal = dmk(n01.x, n01.y, n2p.x);
         if (kind == RT_KIND_PLANE) { PROF_LANES(kp.ctrl, 4); }
+#if SEGMENT_EARLY_LOADS
+        if (kind == RT_KIND_PLANE) mi = plane_material(a01.x, a2r.x, ids.y, ids.z, h.p);
+#else
         if (kind == RT_KIND_PLANE) mi = plane_material(pi->a[0], pi->a[2], ids.y, ids.z, h.p);
+#endif
     }
     const MatD* m = kp.mats + mi;
     const int4 mq = ldi4((const int*)m);               // is_light, gloss_thr, rindex (two words)
+#if SEGMENT_EARLY_LOADS
+    const double2 m_exp = ld2(&m->sexp);               // (specular_exp, 1 / specular_exp)
+    // ... and the previous vertex's material beside the hit's, before the first of them is looked at (a dead end reads it
+    // for nothing)
+    PvMaterial pv_early;
+    pv_early.c01 = pv_early.c2s0 = pv_early.s12 = make_double2(0.0, 0.0); pv_early.sexp = 1.0;
+    if (!pvm && s.nverts > 0) pv_early = load_pv_material(kp, s.pv_mat, s.flags);
+#endif
     const bool is_light = mq.x != 0;
     const unsigned gloss_thr = (unsigned)mq.y;
     const double rindex = __hiloint2double(mq.w, mq.z);
@@ -137,14 +191,17 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
 
     if (s.nverts > 0 && !dead_end) {
         PROF_LANES(kp.ctrl, 5);
-        const MatD* pm = kp.mats + s.pv_mat;
+#if SEGMENT_EARLY_LOADS
+        const PvMaterial pv = pvm ? *pvm : pv_early;
+#else
+        const PvMaterial pv = pvm ? *pvm : load_pv_material(kp, s.pv_mat, s.flags);
+#endif
         d3 w = dnorm(dsub(h.p, s.o));
         double sp;
         const bool pv_reflect = (s.flags & FL_PV_REFLECT) != 0;
-        const double* cs = pv_reflect ? pm->diff : pm->rdiff;       // (diffuse, specular) or the refraction pair
-        const double2 c01 = ld2(cs), c2s0 = ld2(cs + 2), s12 = ld2(cs + 4);
+        const double2 c01 = pv.c01, c2s0 = pv.c2s0, s12 = pv.s12;
         if (pv_reflect) { PROF_LANES(kp.ctrl, 6); }
-        if (pv_reflect) sp = rtm::powd(ddot(s.pv_r, w), pm->sexp);
+        if (pv_reflect) sp = rtm::powd(ddot(s.pv_r, w), pv.sexp);
         else sp = 1.0;
         double dd = ddot(s.pv_n, w);
         if (sp < 0.0) sp = 0.0;
@@ -184,7 +241,11 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         if (!leaving) reflect = rindex == 0.0 || rng_next(s.rng) < 1073741823u;        // main.cpp:164-167: no draw for an opaque solid
         if (reflect) {
             PROF_LANES(kp.ctrl, 9);
+#if SEGMENT_EARLY_LOADS
+            fwd = reflection_dir<POOL>(s.d, normal, gloss_thr, m_exp.y, s.rng, &kp.ctrl[1], item, lobe, retry);
+#else
             fwd = reflection_dir<POOL>(s.d, normal, gloss_thr, m->inv_sexp, s.rng, &kp.ctrl[1], item, lobe, retry);
+#endif
         } else {
             PROF_LANES(kp.ctrl, 10);
             fwd = refraction_dir(s.d, normal, rindex, s.n_cur);
