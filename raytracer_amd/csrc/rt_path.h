@@ -189,6 +189,11 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     const double rindex = __hiloint2double(mq.w, mq.z);
     const bool dead_end = (!is_light) && s.remaining == 0 && kp.has_light;             // main.cpp:137-153: always black
 
+    // A path that ends on an emitter multiplies its factors from the last vertex back.  The last one is computed right
+    // below: it stays in registers (top0..2) instead of being read back from where it has just been stored, and the one
+    // before it is requested here, ahead of that computation.
+    double top0 = 1.0, top1 = 1.0, top2 = 1.0, below0 = 1.0, below1 = 1.0, below2 = 1.0;
+    if (is_light && s.nverts >= 2) fst.get3(s.nverts - 2, below0, below1, below2);
     if (s.nverts > 0 && !dead_end) {
         PROF_LANES(kp.ctrl, 5);
 #if SEGMENT_EARLY_LOADS
@@ -206,7 +211,8 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
         double dd = ddot(s.pv_n, w);
         if (sp < 0.0) sp = 0.0;
         if (dd < 0.0) dd = 0.0;
-        fst.set3(s.nverts - 1, c01.x * dd + c2s0.y * sp, c01.y * dd + s12.x * sp, c2s0.x * dd + s12.y * sp);
+        top0 = c01.x * dd + c2s0.y * sp; top1 = c01.y * dd + s12.x * sp; top2 = c2s0.x * dd + s12.y * sp;
+        fst.set3(s.nverts - 1, top0, top1, top2);
     }
 
     // how the segment ends; every terminating case funnels into ONE end_path call below so that the lanes
@@ -216,7 +222,9 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
     if (is_light) {                                                                    // main.cpp:132-135
         const double2 e01 = ld2(m->ref), e2 = ld2(m->ref + 2);       // (ref0, ref1), (ref2, -)
         c0 = e01.x; c1 = e01.y; c2 = e2.x;
-        for (int k = s.nverts - 1; k >= 0; k--) {
+        if (s.nverts >= 1) { c0 = c0 * top0; c1 = c1 * top1; c2 = c2 * top2; }
+        if (s.nverts >= 2) { c0 = c0 * below0; c1 = c1 * below1; c2 = c2 * below2; }
+        for (int k = s.nverts - 3; k >= 0; k--) {
             PROF_LANES(kp.ctrl, 7);
             double f0, f1, f2;
             fst.get3(k, f0, f1, f2);
