@@ -59,7 +59,7 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
         if (rep) { if (n > 0u) cur = cl[0]; if (n > 1u) nxt = cl[cstride]; }
 #endif
 #if SHADE_REC_AHEAD
-        if (PLACES) {
+        {
             // The candidates as one stream of places, each one's record requested while the one before it is tested: a wave's
             // lanes hold a few candidates each and a dependent read of the table costs a microsecond under load, so the
             // reads, not the tests, set the length of this loop.
@@ -84,7 +84,16 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
                 Rec r;
                 r.place = next_place();
                 r.a01 = make_double2(0.0, 0.0); r.a2r = make_double2(0.0, 0.0); r.idx = 0;
-                if (r.place >= 0) { const double* c = w.kp.mf_cand + 4 * (size_t)r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)w.kp.mf_perm[r.place]; }
+                if (PLACES) {
+                    if (r.place >= 0) { const double* c = w.kp.mf_cand + 4 * (size_t)r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)w.kp.mf_perm[r.place]; }
+                } else {
+                    // lists of file indices: the solid's own record; a place past the list is padding (a NaN radius and its
+                    // index past the list say so below, as for a place without a solid)
+                    r.idx = r.place;
+                    r.a2r = make_double2(0.0, __builtin_nan(""));
+                    if (r.place >= 0 && r.place < w.kp.n_prims) { const PrimD* pr = w.kp.prims + r.place; r.a01 = ld2(pr->a); r.a2r = ld2(pr->a + 2); }
+                    else if (r.place >= 0) r.idx = w.kp.n_prims;
+                }
                 return r;
             };
             Rec q[SHADE_REC_AHEAD + 1];
@@ -100,8 +109,8 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
                 if ((t.a2r.y == t.a2r.y) || t.idx < w.kp.n_prims)
                     consider(narrow_point_from(t.idx, dmk(t.a01.x, t.a01.y, t.a2r.x), t.a2r.y, o, d, w.kp.prims, w.kp.verts), t.idx, o, h);
             }
-        } else
-#endif
+        }
+#else
         for (unsigned e = 0; e < n; e++) {
             const uint2 ent = cur;
             cur = nxt;
@@ -118,6 +127,7 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
                 narrow_place<PLACES>((int)ent.x * BROAD_GROUP + k, o, d, w.kp, h);
             }
         }
+#endif
 #if DIAG_TWICE_CAND
         }
 #endif
