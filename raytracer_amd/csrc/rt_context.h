@@ -90,6 +90,7 @@ struct rt_context {
     uint64_t overlap_min_pixels = 3ull << 20;   // ... for renders of at least this many pixels (RT_OVERLAP_MIN_PIXELS), see render_pipeline
     int last_sub = 1;          // sub-pipelines of the last render
     int broad_mfma = 1;        // 1: the broad phase runs on the matrix cores (broad_mfma_kernel), 0: on the vector ALU (broad_kernel)
+    bool cand_lds = true;      // shade_kernel keeps the scan table's compact records in LDS when they fit (RT_CAND_LDS=0: reads them from memory)
     bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
     int accel = RT_ACCEL_AUTO; // pipeline: candidate lists from the scan of every record (0), from the grid walk (1), or whichever is
                                // faster for the scene (2: the walk above accel_min_bounded bounded solids)
@@ -440,7 +441,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     kp.max_verts = RT_MAXV;
     kp.cmax = h->cmax;
     kp.wide = 0;
-    kp.mf_perm = nullptr; kp.mf_cand = nullptr;
+    kp.mf_perm = nullptr; kp.mf_cand = nullptr; kp.mf_places_lds = 0;
     for (int k = 0; k < 3; k++) kp.T[k] = h->T[k];
     kp.records = (const float4*)h->d_records;
     kp.chunks = (const ChunkDesc*)h->d_chunks;

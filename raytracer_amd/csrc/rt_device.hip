@@ -132,6 +132,7 @@ int rt_create(rt_handle* out, int device) {
     if (const char* e = getenv("RT_ACCEL")) rt_set_option(h, RT_OPT_ACCEL, atoi(e));
     if (const char* e = getenv("RT_ACCEL_MIN_BOUNDED")) h->accel_min_bounded = atoi(e);
     if (const char* e = getenv("RT_NO_BOX")) h->no_box = atoi(e) != 0;
+    if (const char* e = getenv("RT_CAND_LDS")) h->cand_lds = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_CULL")) h->mf_cull = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BINNED")) h->mf_binned = atoi(e) != 0;
     if (const char* e = getenv("RT_MFMA_BEHIND")) h->mf_behind = atoi(e) != 0;
@@ -708,7 +709,16 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         HIP_TRY(h, hipEventRecord(h->fork_ev, st));
         for (int p = 0; p < nsub; p++) HIP_TRY(h, hipStreamWaitEvent(ss[p], h->fork_ev, 0));
     }
-    const size_t shade_lds = (size_t)h->always_doubles * sizeof(double);
+    // shade_kernel's LDS: the always table and, when the scan's table is small enough for four workgroups per CU to hold a
+    // copy each (1024 places: 36 KB), the exact phase's compact records of it -- a candidate's record then comes out of
+    // LDS in a tenth of the time it takes out of the L2
+    size_t shade_lds = (size_t)((h->always_doubles + 1) & ~1) * sizeof(double);
+    int places_lds = 0;
+    if (use_mfma && h->mf_reordered && h->cand_lds && (size_t)h->n_groups * BROAD_GROUP <= 1024u) {
+        places_lds = h->n_groups * BROAD_GROUP;
+        shade_lds += (size_t)places_lds * (4 * sizeof(double) + sizeof(unsigned));
+    }
+    for (int p = 0; p < nsub; p++) wp[p].kp.mf_places_lds = places_lds;
     // the sub-pipelines' batches, enqueued round by round alternately so that neither stream runs ahead on the host
     uint64_t base[RT_MAX_SUB];
     for (int p = 0; p < nsub; p++) base[p] = sub_begin[p];

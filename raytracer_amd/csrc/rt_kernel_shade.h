@@ -25,7 +25,8 @@ namespace {
 constexpr unsigned HEAVY_WORDS = 6, HEAVY_BITS = 48;   // shared out: lists of more than 6 mask words with more than 48 records
 
 template <bool PLACES>
-DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, unsigned long long& ncand_total) {
+DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, const double* cand_lds, const unsigned* perm_lds, bool in_lds,
+                 unsigned long long& ncand_total) {
     const int lane = threadIdx.x & 63;
     Hit h;
     h.q = __builtin_inf(); h.idx = -1;
@@ -85,7 +86,10 @@ DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const d
                 r.place = next_place();
                 r.a01 = make_double2(0.0, 0.0); r.a2r = make_double2(0.0, 0.0); r.idx = 0;
                 if (PLACES) {
-                    if (r.place >= 0) { const double* c = w.kp.mf_cand + 4 * (size_t)r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)w.kp.mf_perm[r.place]; }
+                    if (r.place >= 0) {
+                        if (in_lds) { const double* c = cand_lds + 4 * r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)perm_lds[r.place]; }
+                        else { const double* c = w.kp.mf_cand + 4 * (size_t)r.place; r.a01 = ld2(c); r.a2r = ld2(c + 2); r.idx = (int)w.kp.mf_perm[r.place]; }
+                    }
                 } else {
                     // lists of file indices: the solid's own record; a place past the list is padding (a NaN radius and its
                     // index past the list say so below, as for a place without a solid)
@@ -179,6 +183,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     for (int i = threadIdx.x; i < w.kp.always_doubles; i += SHADE_BLOCK) alw[i] = w.kp.always[i];
+    // behind the always table: the scan table's compact records and file indices, when the host found room for them
+    double* const cand_lds = alw + ((w.kp.always_doubles + 1) & ~1);
+    unsigned* const perm_lds = (unsigned*)(cand_lds + 4 * w.kp.mf_places_lds);
+    const bool in_lds = PLACES && w.kp.mf_places_lds > 0;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < 2 * w.kp.mf_places_lds; i += SHADE_BLOCK) st2(cand_lds + 2 * i, w.kp.mf_cand[2 * i], w.kp.mf_cand[2 * i + 1]);
+        for (int i = threadIdx.x; i < w.kp.mf_places_lds; i += SHADE_BLOCK) perm_lds[i] = w.kp.mf_perm[i];
+    }
     __syncthreads();
 #if SHADE_PROFILE
     // wave-cycles per section (find_hit | segment | barriers | emit), summed over waves into ctrl[16..]
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             rd = dmk(p1.y, p2.x, p2.y);
         }
         SHADE_VIEW(w2);
-        const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, ncand_total);   // whole waves: heavy rays are shared out
+        const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, cand_lds, perm_lds, in_lds, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         SHADE_VIEW(w3);
         PvMaterial pvm;

@@ -72,6 +72,7 @@ struct KParams {
     int wide;                // ray records with the wide error bounds (the broad phase runs on the matrix cores)
     const unsigned* mf_perm; // candidate lists name places of broad_mfma_kernel's record order: place -> file index (null: lists
                              // name file indices)
+    int mf_places_lds;       // places of mf_cand / mf_perm that shade_kernel copies into LDS behind the always table (0: none)
     const double* mf_cand;   // [places][4]: (point a, radius) of the solid at a place, NaN radius for a plane, a face or no solid
     double T[3];             // translation applied before rounding coordinates to float
     const float4* records;
