@@ -138,7 +138,7 @@ enum {
  * Environment variables read here, once per context, for A/B runs and tests (none changes an output bit; the first seven
  * set the same values as rt_set_option): RT_MODE, RT_BLOCK, RT_BROAD_BLOCK, RT_WG_PER_CU, RT_CHUNK_RECORDS, RT_OVERLAP,
  * RT_ACCEL; RT_ACCEL_MIN_BOUNDED, RT_GRID_DENSITY (grid walk); RT_BROAD_MFMA, RT_MFMA_CULL, RT_MFMA_MIN_BOUNDED,
- * RT_MFMA_BINNED, RT_MFMA_BINNED_MIN, RT_MFMA_LIST, RT_MFMA_BEHIND (matrix-core scan); RT_NO_BOX; and, at every render,
+ * RT_MFMA_BINNED, RT_MFMA_BINNED_MIN, RT_MFMA_LIST, RT_MFMA_BEHIND (matrix-core scan); RT_NO_BOX, RT_CAND_LDS; and, at every render,
  * RT_SHADE_GRID; RT_OVERLAP_MIN_PIXELS (pixels of a render from which RT_OPT_OVERLAP applies).  rt_multi_create also reads RT_MULTI_LOOPBACK and RT_MULTI_FORCE_RCCL. */
 int rt_create(rt_handle* out, int device);
 

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
     // behind the always table: the scan table's compact records and file indices, when the host found room for them
     double* const cand_lds = alw + ((w.kp.always_doubles + 1) & ~1);
     unsigned* const perm_lds = (unsigned*)(cand_lds + 4 * w.kp.mf_places_lds);
-    const bool in_lds = PLACES && w.kp.mf_places_lds > 0;
+    // (a copy per workgroup and launch: worth it from the second trip on -- the rounds of a small render have one)
+    const bool in_lds = PLACES && w.kp.mf_places_lds > 0 && count > gridDim.x * blockDim.x;
     if (in_lds) {
         for (int i = threadIdx.x; i < 2 * w.kp.mf_places_lds; i += SHADE_BLOCK) st2(cand_lds + 2 * i, w.kp.mf_cand[2 * i], w.kp.mf_cand[2 * i + 1]);
         for (int i = threadIdx.x; i < w.kp.mf_places_lds; i += SHADE_BLOCK) perm_lds[i] = w.kp.mf_perm[i];
