@@ -26,12 +26,12 @@ constexpr unsigned HEAVY_WORDS = 6, HEAVY_BITS = 48;   // shared out: lists of m
 
 template <bool PLACES>
 DEV Hit find_hit(const WfParams& w, unsigned pos, bool live, d3 o, d3 d, const double* alw, const double* cand_lds, const unsigned* perm_lds, bool in_lds,
-                 unsigned long long& ncand_total) {
+                 unsigned n_list, unsigned long long& ncand_total) {
     const int lane = threadIdx.x & 63;
     Hit h;
     h.q = __builtin_inf(); h.idx = -1;
     h.p = dmk(__builtin_inf(), __builtin_inf(), __builtin_inf());
-    const unsigned n = live ? w.cand_cnt[(size_t)(w.iter & 1) * w.slots + pos] : 0u;
+    const unsigned n = live ? n_list : 0u;          // the list's length, read by the caller beside (or ahead of) the ray
     const uint2* cl = w.cand + pos;
     const size_t cstride = w.slots;
     bool heavy = n > (unsigned)WF_CAND_CAP;     // WF_OVERFLOW, or a shared list's count that passed the capacity
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
         d3 ro = dmk(0, 0, 0), rd = dmk(0, 0, 1);
         unsigned rng0 = 0;
         SHADE_VIEW(w1);
+        // the candidate list's length: asked for before the camera ray is worked out (first round) or with the ray's own reads
+        unsigned n_list = 0u;
+        if (live) n_list = w1.cand_cnt[(size_t)qi * w1.slots + pos];
         if (FIRST) {
             if (live) {
                 // only the ray and the RNG state stay in registers during the closest-hit search
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES * 256 / SHADE_BLOCK) void 
             rd = dmk(p1.y, p2.x, p2.y);
         }
         SHADE_VIEW(w2);
-        const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, cand_lds, perm_lds, in_lds, ncand_total);   // whole waves: heavy rays are shared out
+        const Hit h = find_hit<PLACES>(w2, pos, live, ro, rd, alw, cand_lds, perm_lds, in_lds, n_list, ncand_total);   // whole waves: heavy rays are shared out
         SHADE_TICK(1);
         SHADE_VIEW(w3);
         PvMaterial pvm;
