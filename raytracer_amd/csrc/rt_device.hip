@@ -714,9 +714,12 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     // LDS in a tenth of the time it takes out of the L2
     size_t shade_lds = (size_t)((h->always_doubles + 1) & ~1) * sizeof(double);
     int places_lds = 0;
-    if (use_mfma && h->mf_reordered && h->cand_lds && (size_t)h->n_groups * BROAD_GROUP <= 1024u) {
-        places_lds = h->n_groups * BROAD_GROUP;
-        shade_lds += (size_t)places_lds * (4 * sizeof(double) + sizeof(unsigned));
+    if (use_mfma && h->mf_reordered && h->cand_lds) {
+        const size_t extra = (size_t)h->n_groups * BROAD_GROUP * (4 * sizeof(double) + sizeof(unsigned));
+        if (shade_lds + extra <= (size_t)40 * 1024) {          // a quarter of a CU's 160 KB: the kernel's four workgroups per CU stay
+            places_lds = h->n_groups * BROAD_GROUP;
+            shade_lds += extra;
+        }
     }
     for (int p = 0; p < nsub; p++) wp[p].kp.mf_places_lds = places_lds;
     // the sub-pipelines' batches, enqueued round by round alternately so that neither stream runs ahead on the host
