@@ -277,15 +277,16 @@ DEV bool segment(PathState& s, const Hit& h, const FStack& fst, unsigned item, u
 // way round and is still tested as a sphere).
 DEV d3 narrow_point_from(int idx, d3 a, double radius, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
     if (radius == radius) return sphere_point(a, radius, o, d);
+    // the rest of the record in one go (kind and vertex range, vertex count, normal): reads that wait for one another are
+    // what a plane or a face costs.  (a, radius) ARE the record's first 32 bytes: a sphere that gets here has a NaN radius.
     const PrimD* pr = prims + idx;
     const int4 ids = ldi4(&pr->kind);                  // kind, mat0, mat1, voff
-    const double2 p01 = ld2(pr->a), p2r = ld2(pr->a + 2);
-    const d3 pa = dmk(p01.x, p01.y, p2r.x);
-    if (ids.x == RT_KIND_SPHERE) return sphere_point(pa, p2r.y, o, d);
+    const int vcnt = pr->vcnt;
     const double2 n01 = ld2(pr->n), n2p = ld2(pr->n + 2);
+    if (ids.x == RT_KIND_SPHERE) return sphere_point(a, radius, o, d);
     const d3 n = dmk(n01.x, n01.y, n2p.x);
-    if (ids.x == RT_KIND_PLANE) return plane_point(pa, n, o, d);
-    return face_point(pa, n, pr->vcnt, verts + ids.w, o, d);
+    if (ids.x == RT_KIND_PLANE) return plane_point(a, n, o, d);
+    return face_point(a, n, vcnt, verts + ids.w, o, d);
 }
 DEV d3 narrow_point(int idx, d3 o, d3 d, const PrimD* prims, const FaceV* verts) {
     const PrimD* pr = prims + idx;
