@@ -130,13 +130,12 @@ DEV d3 plane_point(d3 P, d3 n, d3 o, d3 d) {
 // same -- a rejected point is a rejected point -- and every vertex is a read that the next one waits behind (a quad's four
 // were four microseconds of a wave's time; requesting a vertex one ahead costs 15 spilled registers and gains nothing).
 DEV d3 face_point(d3 a, d3 n, int num, const FaceV* v, d3 o, d3 d) {
-    // (the first vertex is requested before the plane's point is worked out: a face has at least one)
-    double2 q0 = ld2(v->v), q1 = ld2(v->v + 2), q2 = ld2(v->v + 4), q3 = ld2(v->v + 6);   // v0 v1 | v2 e0 | e1 e2 | to_next -
     d3 p = plane_point(a, n, o, d);
     if (dnan(p.x)) return p;                 // plane missed: every comparison below would be false anyway
     bool miss = false;
     for (int i = 0; i < num && !miss; i++) {
-        if (i > 0) { const double* f = v[i].v; q0 = ld2(f); q1 = ld2(f + 2); q2 = ld2(f + 4); q3 = ld2(f + 6); }
+        const double* f = v[i].v;
+        const double2 q0 = ld2(f), q1 = ld2(f + 2), q2 = ld2(f + 4), q3 = ld2(f + 6);   // v0 v1 | v2 e0 | e1 e2 | to_next -
         double to_p = ddot(dmk(q1.y, q2.x, q2.y), dsub(dmk(q0.x, q0.y, q1.x), p));
         if (to_p * q3.x < 0.0) miss = true;
     }
