@@ -220,6 +220,14 @@ DEV unsigned mf_signs_behind(const f32x16& hb, const f32x16& n, float tmv, float
     return m;
 }
 
+// The ray record at queue position pos, or `none` for a lane without a ray: the lane then reads position 0 (a queue that
+// is scanned has one) and drops what it read -- a read under the condition is cut into one-word reads behind a branch each.
+DEV void mf_load_ray(const float4* __restrict__ rec0, const float4* __restrict__ rec1, unsigned pos, bool valid, const float4 none, float4& ra, float4& rb) {
+    const unsigned p = valid ? pos : 0u;
+    const float4 a = rec0[p], b = rec1[p];
+    ra = valid ? a : none; rb = valid ? b : none;
+}
+
 constexpr int MF_TILES = 2;                   // ray tiles (of 32 rays) per wave and batch
 
 // For a lane of the lower half: the value of its partner lane (lane + 32).  v_permlane32_swap exchanges the upper half
@@ -260,7 +268,8 @@ DEV void mf_scan_window(const WfParams& w, const uint4* mf_lds, float scale, uns
             pos[t] = batch * per_block + (unsigned)(wv * MF_TILES + t) * 32u + (unsigned)r;
             const bool valid = pos[t] < count;
             const float4 none = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
-            const float4 ra = valid ? w.rec[0][pos[t]] : none, rb = valid ? w.rec[1][pos[t]] : none;
+            float4 ra, rb;
+            mf_load_ray(w.rec[0], w.rec[1], pos[t], valid, none, ra, rb);
             const bool ordinary = mf_ordinary(ra, rb, scale);
             rf[t] = mf_ray_frag(ra, rb, scale, h, ordinary);
             own[t] = valid && h == 0;                 // the lower lane half appends for the ray
@@ -401,6 +410,31 @@ constexpr int MFB_LIST = 192;                  // places in a group's ray list; 
 #ifndef MFB_WRITELANE
 #define MFB_WRITELANE 1     // 0: the ballot words reach their lanes through compare + select
 #endif
+#ifndef MFB_TRANSPOSE
+#define MFB_TRANSPOSE 1     // 0: the (ray, group) bit matrix is turned round by 32 ballots, each written into its two lanes
+#endif
+// The 32 x 32 bit matrix held by each half of the wave (lane r, bit b), transposed: lane k of the half receives in bit r
+// what lane r held in bit k.  Five exchanges of off-diagonal blocks (16, 8, 4, 2, 1): a lane takes its partner's word
+// (lane ^ j, through the LDS crossbar: no memory is touched), rotates it by j towards the bits it is to fill and inserts
+// those bits -- three instructions per step.
+template <int J, int LOG2J>
+DEV unsigned mf_transpose_step(unsigned x, int lane) {
+    constexpr unsigned M = J == 16 ? 0x0000ffffu : J == 8 ? 0x00ff00ffu : J == 4 ? 0x0f0f0f0fu : J == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & J) == 0
+    const unsigned y = (unsigned)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1f);      // lane ^ J
+    const unsigned u = (unsigned)__builtin_amdgcn_sbfe(lane, LOG2J, 1);                      // all ones in the lanes with (lane & J) != 0
+    // those lanes fill the bits with (b & J) == 0 from y's bit b + J, the others the bits with (b & J) != 0 from y's bit b - J
+    const unsigned rot = __builtin_amdgcn_alignbit(y, y, (u & (unsigned)J) | (~u & (unsigned)(32 - J)));
+    const unsigned keep = M ^ u;
+    return (x & keep) | (rot & ~keep);
+}
+DEV unsigned mf_transpose32(unsigned x, int lane) {
+    asm volatile("" : "+v"(lane));        // the lanes' masks are worked out here, not kept in registers by a caller's loop
+    x = mf_transpose_step<16, 4>(x, lane);
+    x = mf_transpose_step<8, 3>(x, lane);
+    x = mf_transpose_step<4, 2>(x, lane);
+    x = mf_transpose_step<2, 1>(x, lane);
+    return mf_transpose_step<1, 0>(x, lane);
+}
 #ifndef MFB_WIDE
 #define MFB_WIDE 1          // 0: every wave prepares 32 rays, both lane halves building the same ray's pieces (scan +0.11 ms per C3 frame)
 #endif
@@ -453,7 +487,8 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
 #else
                 const WfParams& wa = w_arg;
 #endif
-                const float4 ra = valid ? wa.rec[0][pos] : none, rb = valid ? wa.rec[1][pos] : none;
+                float4 ra, rb;
+                mf_load_ray(wa.rec[0], wa.rec[1], pos, valid, none, ra, rb);
                 float tmv = __builtin_inff(), mr = 0.0f;      // the behind test's constants, in the table's scaled lengths
                 if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
                 const bool ordinary = mf_ordinary(ra, rb, scale);
@@ -502,6 +537,10 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 const unsigned up = mf_from_lower_half(full1);                // lane 32 + r: the word of ray 32 + r
                 const unsigned gm = own ? (h == 0 ? full0 : up) : 0u;
                 // group k's rays of this wave as a 64-bit ballot; its lower word goes to lane k, its upper word to lane k + 32
+#if MFB_TRANSPOSE
+                // (group k is bit 31 - k of a ray's word)
+                unsigned bw = mf_transpose32(__builtin_bitreverse32(gm), lane);
+#else
                 unsigned bw = 0;
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
@@ -510,6 +549,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                     asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
                                  : "+v"(bw) : "s"((unsigned)b), "s"((unsigned)(b >> 32)), "i"(k), "i"(k + 32));
                 }
+#endif
                 // lanes k and k + 32 share one reservation in group k's list: the lower lane asks for both
                 const unsigned cnt = (unsigned)__popc(bw);
                 const unsigned cnt_hi = mf_from_upper_half(cnt);
@@ -535,7 +575,8 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
 #else
             const WfParams& wa = w_arg;
 #endif
-            const float4 ra = valid ? wa.rec[0][pos] : none, rb = valid ? wa.rec[1][pos] : none;
+            float4 ra, rb;
+            mf_load_ray(wa.rec[0], wa.rec[1], pos, valid, none, ra, rb);
             float tmv = __builtin_inff(), mr = 0.0f;          // the behind test's constants, in the table's scaled lengths
             if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
             const bool ordinary = mf_ordinary(ra, rb, scale);
