@@ -207,15 +207,18 @@ DEV unsigned mf_signs(const f32x16& hb, const f32x16& n) {
 }
 
 // mf_signs for group records with the behind test of broad_setup: a group whose bounding sphere lies wholly behind the
-// ray's origin (hbt = hb - tmv > 0 and hbt^2 > (s - thr) + mr; both false for a NaN or an infinite tmv) is not kept
+// ray's origin (hbt = hb - tmv >= 0 and hbt^2 > (s - thr) + mr; never with an infinite tmv; the callers replace a NaN by that) is not kept
 DEV unsigned mf_signs_behind(const f32x16& hb, const f32x16& n, float tmv, float mr) {
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
+        // On sign bits, no compare and no select: kept = tt < 0 and not (hbt >= 0 and mr - (hbt^2 + tt) < 0).  A difference
+        // that is zero comes out as +0 (not behind); hbt = +0 counts as in front, which the derivation allows (B >= 0 and
+        // B^2 > disc leave no root at or past the origin either).
         const float tt = __builtin_fmaf(-hb[i], hb[i], n[i]);
         const float hbt = hb[i] - tmv;
-        const bool behind = (hbt > 0.0f) & (__builtin_fmaf(hbt, hbt, tt) > mr);
-        m = __builtin_amdgcn_alignbit(m, behind ? 0u : __float_as_uint(tt), 31u);
+        const float y = mr - __builtin_fmaf(hbt, hbt, tt);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(tt) & (__float_as_uint(hbt) | ~__float_as_uint(y)), 31u);
     }
     return m;
 }
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 mf_load_ray(wa.rec[0], wa.rec[1], pos, valid, none, ra, rb);
                 float tmv = __builtin_inff(), mr = 0.0f;      // the behind test's constants, in the table's scaled lengths
                 if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
+                if (!(tmv == tmv) || !(mr == mr)) { tmv = __builtin_inff(); mr = 0.0f; }      // (the sign-bit form of the test has no NaN case of its own)
                 const bool ordinary = mf_ordinary(ra, rb, scale);
                 uint4 fr4[4];
                 mf_ray_frag_both(ra, rb, scale, ordinary, fr4);
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             mf_load_ray(wa.rec[0], wa.rec[1], pos, valid, none, ra, rb);
             float tmv = __builtin_inff(), mr = 0.0f;          // the behind test's constants, in the table's scaled lengths
             if (valid && behind) { const float2 t = wa.tm[pos]; tmv = t.x * scale; mr = t.y * scale * scale; }
+            if (!(tmv == tmv) || !(mr == mr)) { tmv = __builtin_inff(); mr = 0.0f; }
             const bool ordinary = mf_ordinary(ra, rb, scale);
             const RayFrag rf = mf_ray_frag(ra, rb, scale, h, ordinary);
             F16Pack p0, p1;
