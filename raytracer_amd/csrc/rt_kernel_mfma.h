@@ -447,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
     const WfParams& w = w_arg;
     constexpr int NW = BLOCK / 64, RAYS = NW * 32;
     constexpr int NBUILD = NW / 2;                         // MFB_WIDE: the waves that prepare a pass's rays, 64 each
-    constexpr unsigned SKIP = 0xffffffffu;
+    constexpr unsigned SKIP = 0x80000000u;                 // a list length from here on: not a list (the appends count on from it and never store)
     const unsigned count = w.counts[w.iter];
     if (count == 0) return;
     unsigned* const cand_cnt = w.cand_cnt + (size_t)(w.iter & 1) * w.slots;
@@ -462,7 +462,8 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
     unsigned short* const lists = (unsigned short*)(rayf + (RAYS + 1) * 4);     // fragment RAYS: zeros, for the places of an item no ray fills
     unsigned* const rcnt = (unsigned*)(lists + MFB_GROUPS * MFB_LIST);
     unsigned* const gcount2 = rcnt + RAYS;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    // (the wave's number as a scalar: what follows from it -- item numbers, their groups and chunks -- then stays out of the vector unit)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), h = lane >> 5, r = lane & 31;
     unsigned pass = 0, tiles_done = 0;                     // (32 rays x 32 records) products of this wave
     for (int win = 0; win < n_windows; win++) {
         const int g0 = win * win_groups;
@@ -659,8 +660,8 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             uint2* const cand = wc.cand;
             const size_t cstride = wc.slots;
             for (unsigned item = (unsigned)wv; item < total; item += NW) {     // items cost the same: dealt out in turn
-                const unsigned long long in = __ballot(lane < 32 && start <= item && item < incl);
-                const int g = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(in));
+                // the item's group: the first whose range ends past it (the ends ascend over the lanes 0..31)
+                const int g = (int)__popcll(__ballot(incl <= item) & 0xffffffffull);
                 const unsigned c = item - (unsigned)__builtin_amdgcn_readlane((int)start, g);
                 const unsigned cgg = (unsigned)__builtin_amdgcn_readlane((int)cg, g);
                 const bool all_rays = cgg > (unsigned)list_cap;
@@ -676,8 +677,9 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
                 mf_products(gfr[g * MF_GROUP_WORDS + lane], q, hb, nn);
                 const unsigned mine = mf_signs(hb, nn);
                 const unsigned full = (mine << 16) | mf_from_upper_half(mine);
-                // (a ray without a list of its own -- none here, not ordinary -- has zero fragments, but its rcnt says SKIP)
-                if (h == 0 && have && full != 0u && rcnt[id] != SKIP) {
+                // (a ray without a list of its own -- none here, not ordinary -- has zero fragments in a dense group's item; its
+                // counter starts at SKIP, far past the capacity: no read of the counter ahead of the atomic)
+                if (h == 0 && have && full != 0u) {
                     const unsigned at = atomicAdd(&rcnt[id], 1u);
                     if (at < (unsigned)WF_CAND_CAP) cand[(size_t)at * cstride + (batch * RAYS + id)] = make_uint2((unsigned)(g0 + g), full);
                 }
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             // ---- the rays' list lengths, by the lanes that own the rays (they set the next pass's start values next)
             if (MFB_WIDE ? valid : h == 0) {
                 const unsigned n1 = rcnt[local];
-                if (n1 != SKIP) cand_cnt[pos] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
+                if (n1 < SKIP) cand_cnt[pos] = n1 > (unsigned)WF_CAND_CAP ? WF_OVERFLOW : n1;
             }
         }
     }
