@@ -251,6 +251,17 @@ DEV unsigned mf_wave_or(unsigned v) {
            (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// Inclusive sums over the lanes of each half of the wave (lane l receives v of lanes 32 (l / 32) .. l): four shifted adds
+// within the rows of 16 lanes, then the lower row's total into the upper row -- data-parallel primitives, no LDS trip.
+DEV unsigned mf_prefix32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
 // CULL: the groups' own bounding spheres ("group records", gn_window of them in fragments that follow the window's
 // groups in LDS) are tested first, and a group is scanned for a tile only if some ray of the tile keeps its group
 // record.  Worth its two extra passes per tile only while the rays of a tile run side by side: the camera rays' round.
@@ -643,11 +654,7 @@ __global__ __launch_bounds__(BLOCK, 8) void broad_mfma_binned_kernel(const WfPar
             const unsigned cg = (lane < gn) ? gcount[lane] : 0u;
             const bool dense = cg > (unsigned)list_cap;
             const unsigned chunks = dense ? (unsigned)NW : (cg + 31u) >> 5;
-            unsigned incl = chunks;
-            for (int off = 1; off < 32; off <<= 1) {
-                const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
-                if ((lane & 31) >= off) incl += up;
-            }
+            const unsigned incl = mf_prefix32(chunks);
             const unsigned start = incl - chunks;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
             if (threadIdx.x < MFB_GROUPS) gcount2[((pass & 1u) ^ 1u) * MFB_GROUPS + threadIdx.x] = 0u;     // the next pass's counters
