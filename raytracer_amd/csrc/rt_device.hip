@@ -612,10 +612,6 @@ static int ensure_pipeline(rt_handle h, rt_context::PipeBufs& b, size_t slots, i
     return RT_OK;
 }
 
-__global__ void set_count_kernel(unsigned* counts, unsigned n_counts, unsigned first) {
-    for (unsigned i = threadIdx.x; i < n_counts; i += blockDim.x) counts[i] = (i == 0) ? first : 0u;
-}
-
 static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids, hipStream_t st) {
     const int rows = rt_rows_for_rank(h->height, tile_rows, rank, world);
     const uint64_t total = (uint64_t)rows * (uint64_t)h->width;
@@ -736,11 +732,10 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
             WfParams& w = wp[p];
             w.slots = (unsigned)n[p];
             w.item_base = (unsigned)base[p];
-            hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(256), 0, ss[p], w.counts, (unsigned)iters + 2u, (unsigned)n[p]);
             w.iter = 0;
             unsigned igrid = (unsigned)((n[p] + 255) / 256);
             if (igrid > (unsigned)h->cu_count * 16u) igrid = (unsigned)h->cu_count * 16u;
-            hipLaunchKernelGGL(init_kernel, dim3(igrid), dim3(256), 0, ss[p], w);
+            hipLaunchKernelGGL(init_kernel, dim3(igrid), dim3(256), 0, ss[p], w, (unsigned)iters + 2u);
         }
         if (!any) break;
         for (int it = 0; it < iters; it++) {

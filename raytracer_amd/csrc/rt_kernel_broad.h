@@ -141,7 +141,10 @@ DEV void start_state(const WfParams& w, unsigned slot, PathState& s) {
 
 // Queue 0 = every pixel slot in order.  Only what broad_kernel reads is written: the float ray record and a zero entry
 // count; the first round's shade_kernel rebuilds the start state itself (start_state).
-__global__ __launch_bounds__(256) void init_kernel(const WfParams w) {
+// The first workgroup also sets the rounds' ray counts (all slots enter round 0, the later counts start at zero: the
+// kernels that add to them come after this one in the stream) -- no launch of its own for that at a frame's start.
+__global__ __launch_bounds__(256) void init_kernel(const WfParams w, unsigned n_counts) {
+    if (blockIdx.x == 0) for (unsigned i = threadIdx.x; i < n_counts; i += blockDim.x) w.counts[i] = (i == 0) ? w.slots : 0u;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < w.slots; slot += stride) {
         PathState s;
