@@ -324,6 +324,9 @@ def main():
                                    "(HIP events around every launch)" % sh["source"]})
             if sh.get("active_inst_valu"):
                 shade["lanes_active_of_64"] = sh.get("thread_cycles_valu", 0.0) / sh["active_inst_valu"]
+                # how much of the time the vector ALUs are issuing at all: the counter is in units of four cycles per SIMD
+                shade["valu_busy_frac"] = 4.0 * sh["active_inst_valu"] / (1024 * 2.4e9 * shade_ms * 1e-3)
+                shade["valu_busy_basis"] = "4 x SQ_ACTIVE_INST_VALU of %s / (1024 SIMDs x 2.4 GHz x shade_kernel time measured here)" % sh["source"]
             if sh.get("insts"):
                 shade["salu_share_of_instructions"] = sh.get("salu_insts", 0.0) / sh["insts"]
         if sh.get("bytes_per_frame") and shade_ms:
