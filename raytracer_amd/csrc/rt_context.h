@@ -429,6 +429,29 @@ bool build_grid(int n_prims, const std::vector<PrimD>& pd, const std::vector<dou
     return true;
 }
 
+// Multiplier and shift for n / d, 0 <= n <= n_max < 2^31: with l = ceil(log2 d) and M = ceil(2^(31 + l) / d) the product n M
+// is off from n 2^(31 + l) / d by less than one unit of the quotient, so (n M) >> (31 + l) is the quotient (M < 2^32:
+// mul-high, then a shift by l - 1).  Checked here at every multiple of d up to n_max; mul = 0 asks for the division.
+inline void div_magic(unsigned d, unsigned long long n_max, unsigned& mul, unsigned& sh) {
+    mul = 0; sh = 0;
+    if (d < 2 || n_max >= (1ull << 31)) return;
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    const unsigned long long M = ((1ull << (31 + l)) + d - 1) / d;
+    if (M >> 32) return;
+    for (unsigned long long k = 0; k * d <= n_max; k++) {
+        const unsigned long long lo = k * d, hi = lo + d - 1 < n_max ? lo + d - 1 : n_max;
+        if (((lo * M) >> (31 + l)) != k || ((hi * M) >> (31 + l)) != k) return;
+    }
+    mul = (unsigned)M; sh = l - 1;
+}
+// after width, height and tile_rows of kp are final
+inline void set_pixel_map(KParams& kp) {
+    const unsigned long long pixels = (unsigned long long)(kp.width > 0 ? kp.width : 1) * (unsigned long long)(kp.height > 0 ? kp.height : 1);
+    div_magic((unsigned)kp.width, pixels, kp.div_w_mul, kp.div_w_sh);
+    div_magic((unsigned)kp.tile_rows, (unsigned long long)(kp.height > 0 ? kp.height : 1), kp.div_t_mul, kp.div_t_sh);
+}
+
 void fill_kparams(rt_context* h, KParams& kp) {
     memset(&kp, 0, sizeof(kp));
     kp.width = h->width; kp.height = h->height; kp.spp = h->spp; kp.depth = h->depth;
@@ -436,6 +459,7 @@ void fill_kparams(rt_context* h, KParams& kp) {
     for (int k = 0; k < 3; k++) kp.cam[k] = h->cam[k];
     kp.has_light = h->has_light; kp.light_draws = h->light_draws;
     kp.tile_rows = 1; kp.rank = 0; kp.world = 1;
+    set_pixel_map(kp);
     kp.nchunks = h->nchunks;
     kp.n_prims = h->n_prims;
     kp.max_verts = RT_MAXV;

@@ -556,6 +556,7 @@ static int render_single_kernel(rt_handle h, int stream_mode, int tile_rows, int
     KParams kp;
     fill_kparams(h, kp);
     kp.tile_rows = tile_rows; kp.rank = rank; kp.world = world;
+    set_pixel_map(kp);
     kp.stream_mode = stream_mode;
     if (stream_mode) {
         kp.n_streams = h->num_threads;
@@ -643,6 +644,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
         const rt_context::PipeBufs& b = h->pb[p];
         fill_kparams(h, w.kp);
         w.kp.tile_rows = tile_rows; w.kp.rank = rank; w.kp.world = world;
+        set_pixel_map(w.kp);
         w.kp.max_verts = verts;
         w.kp.total_items = (unsigned)total;
         w.kp.rgb = d_rgb; w.kp.hit_ids = d_hit_ids;

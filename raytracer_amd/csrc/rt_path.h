@@ -435,10 +435,15 @@ DEV bool narrow_always(const double* tab, int n_always, int n_box, d3 o, d3 d, c
     return odd;
 }
 
+// n / d for n below 2^31 through the multiplier and shift that the host worked out for d (and checked): the divisors here are
+// the same for every pixel of a render, and a quotient by a run-time divisor is some twenty instructions, several of them
+// at a quarter of the rate
+DEV unsigned div_by(unsigned n, unsigned d, unsigned mul, unsigned sh) { return mul ? __umulhi(n, mul) >> sh : n / d; }
 DEV void map_item_to_pixel(unsigned item, const KParams& kp, int& px, int& py) {
-    const int lr = (int)(item / (unsigned)kp.width);
+    const int lr = (int)div_by(item, (unsigned)kp.width, kp.div_w_mul, kp.div_w_sh);
     px = (int)(item - (unsigned)lr * (unsigned)kp.width);
-    py = ((lr / kp.tile_rows) * kp.world + kp.rank) * kp.tile_rows + lr % kp.tile_rows;
+    const int tile = (int)div_by((unsigned)lr, (unsigned)kp.tile_rows, kp.div_t_mul, kp.div_t_sh);
+    py = (tile * kp.world + kp.rank) * kp.tile_rows + (lr - tile * kp.tile_rows);
 }
 
 enum { ST_NEED = 0, ST_ALIVE = 1, ST_DEAD = 2 };

@@ -63,6 +63,8 @@ struct KParams {
     unsigned frame_seed;
     int has_light, light_draws;
     int tile_rows, rank, world;
+    // quotients by width and by tile_rows as a multiply-high and a shift (set_pixel_map on the host; mul = 0: divide)
+    unsigned div_w_mul, div_w_sh, div_t_mul, div_t_sh;
     int stream_mode, n_streams;
     unsigned total_items;
     int nchunks;
