@@ -48,6 +48,12 @@ int rt_mfma_record_pieces(const double* record, double cmax, double* scale, doub
 int rt_mfma_table_order(int n, const double* centres, const double* radii, int reorder, uint32_t* perm, int perm_cap,
                         double* group_spheres, int group_cap);
 
+/* Host-only self-test (no GPU call): the multiplier and shift by which the kernels take n / d for the two divisors of the
+ * pixel map (the frame's width, the tile's rows; main.cpp:250-251 walks the same pixels with a counter): for every
+ * 0 <= n <= n_max, n / d == (uint32_t)(((uint64_t)n * mul) >> 32) >> shift.  Returns 1 when such a pair exists (d >= 2,
+ * n_max < 2^31; the library has checked it at every multiple of d), 0 when the kernels divide instead, < 0 on error. */
+int rt_pixel_map_divisor(uint32_t d, uint64_t n_max, uint32_t* mul, uint32_t* shift);
+
 /* Self-test of the broad phase on the matrix cores: every one of n_rays rays against every one of n_rec bounding spheres,
  * evaluated exactly as broad_mfma_kernel does.  masks: uint32[n_rays * ceil(n_rec / 32)] (HOST); bit 31 - k of
  * masks[ray * groups + g] is set iff record 32 g + k is kept for the ray. */

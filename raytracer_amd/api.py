@@ -30,7 +30,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_SCENE",
 EXPORTS = ("rt_create", "rt_destroy", "rt_set_option", "rt_upload_scene", "rt_rows_for_rank", "rt_render_rows_device",
            "rt_render_streams_device", "rt_finish", "rt_stream_rays", "rt_render", "rt_render_streams", "rt_expose_device", "rt_render_image",
            "rt_expose_bits_device", "rt_expose_rows_device", "rt_expose_device_noalloc",
-           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces", "rt_mfma_table_order",
+           "rt_last_timing", "rt_last_error", "rt_selftest_math", "rt_selftest_broad", "rt_selftest_broad_mfma", "rt_face_bound", "rt_mfma_record_pieces", "rt_mfma_table_order", "rt_pixel_map_divisor",
            "rt_multi_create", "rt_multi_destroy", "rt_multi_gpus", "rt_multi_set_option", "rt_multi_upload_scene",
            "rt_multi_render_image", "rt_multi_render_begin", "rt_multi_render_end", "rt_multi_last_ms", "rt_multi_last_times",
            "rt_multi_uses_rccl", "rt_multi_last_error", "rt_gather_source_row")
@@ -134,10 +134,21 @@ def load_library(path: str = LIB_PATH):
     l.rt_mfma_table_order.argtypes = [C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint32), C.c_int, dp, C.c_int]
     l.rt_mfma_record_pieces.restype = C.c_int
     l.rt_mfma_record_pieces.argtypes = [dp, C.c_double, C.POINTER(C.c_double), dp]
+    l.rt_pixel_map_divisor.restype = C.c_int
+    l.rt_pixel_map_divisor.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     l.rt_face_bound.restype = C.c_int
     l.rt_face_bound.argtypes = [C.c_int, dp, dp, dp, dp]
     _lib = l
     return l
+
+
+def pixel_map_divisor(d, n_max):
+    """(mul, shift) with n // d == ((n * mul) >> 32) >> shift for 0 <= n <= n_max, or None when the kernels divide.  Host only."""
+    mul, sh = C.c_uint32(0), C.c_uint32(0)
+    rc = load_library().rt_pixel_map_divisor(int(d), int(n_max), C.byref(mul), C.byref(sh))
+    if rc < 0:
+        raise RtError(rc, "rt_pixel_map_divisor: bad argument")
+    return (int(mul.value), int(sh.value)) if rc == 1 else None
 
 
 def face_bound(verts, normal):

@@ -193,6 +193,14 @@ void rt_destroy(rt_handle h) {
 
 const char* rt_last_error(rt_handle h) { return h ? h->err.c_str() : "null handle"; }
 
+int rt_pixel_map_divisor(uint32_t d, uint64_t n_max, uint32_t* mul, uint32_t* shift) {
+    if (!mul || !shift || d == 0) return RT_ERR_ARG;
+    unsigned m = 0, s = 0;
+    div_magic(d, n_max, m, s);
+    *mul = m; *shift = s;
+    return m ? 1 : 0;
+}
+
 int rt_face_bound(int n_verts, const double* verts, const double* normal, double* centre, double* radius) {
     if (n_verts < 1 || !verts || !normal || !centre || !radius) return RT_ERR_ARG;
     return face_bound(verts, n_verts, normal, centre, radius) ? 1 : 0;

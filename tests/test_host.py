@@ -375,3 +375,22 @@ def test_gather_source_row_matches_the_partition():
         assert np.array_equal(got, want), (h, t, w)
         assert sum(lib.rt_rows_for_rank(h, t, r, w) for r in range(w)) == h
     assert lib.rt_gather_source_row(10, 0, 2, 5, 0) < 0 and lib.rt_gather_source_row(10, 2, 2, 5, 10) < 0
+
+
+def test_pixel_map_divisors_reproduce_the_quotient():
+    """The kernels take item / width and row / tile_rows through a multiplier and a shift the library works out
+    (rt_pixel_map_divisor; the reference walks the same pixels with a counter, main.cpp:250-251): equal to the integer
+    quotient at every multiple of the divisor, one below it, and a random sample."""
+    rng = np.random.default_rng(5)
+    for d, n_max in [(2, 4096), (3, 10 ** 6), (7, 2160), (8, 4320), (37, 37 * 41 - 1), (192, 192 * 108), (1920, 1920 * 1080),
+                     (3840, 3840 * 2160), (7680, 7680 * 4320), (65535, 2 ** 31 - 1), (2 ** 16, 2 ** 31 - 1), (46341, 2 ** 31 - 1)]:
+        got = api.pixel_map_divisor(d, n_max)
+        assert got is not None, (d, n_max)
+        mul, sh = got
+        k = np.arange(0, n_max // d + 1, dtype=np.uint64)
+        n = np.unique(np.clip(np.concatenate([k * d, k * d + (d - 1), np.maximum(k * d, 1) - 1,
+                                              rng.integers(0, n_max + 1, 20000).astype(np.uint64)]), 0, n_max))
+        q = ((n * np.uint64(mul)) >> np.uint64(32)) >> np.uint64(sh)
+        assert np.array_equal(q, n // np.uint64(d)), (d, n_max)
+    assert api.pixel_map_divisor(1, 100) is None            # the kernels divide (by one)
+    assert api.pixel_map_divisor(5, 2 ** 31) is None        # beyond the range the multiplier is proven for
