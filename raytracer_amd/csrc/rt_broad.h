@@ -28,6 +28,11 @@ constexpr float BROAD_WIDE_EH = 64.0f, BROAD_WIDE_E0 = 96.0f;
 constexpr float BROAD_WIDE_DELTA = 6.0e-6f;    // the applied scale 1.0000035^2 - 1 = 7.0e-6 is larger
 constexpr float BROAD_WIDE_SCALE = 1.0000035f;
 
+// Square root for the bounds of the conservative tests: the hardware's own (v_sqrt_f32, within one unit in the last place)
+// instead of the correctly rounded one, which is a dozen instructions more.  Every use leaves room for that unit: a factor
+// 1.0001 on |o|, bounds with a threefold margin over the term-by-term count.
+DEV float bound_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 struct RayRec {
     float4 a;   // -d' (xyz), od'
     float4 b;   // 2 o (xyz), thr
@@ -63,7 +68,7 @@ DEV RayRec broad_setup(d3 o, d3 d, const double* T, float cmax, bool wide = fals
     const float fx = (float)d.x * scale, fy = (float)d.y * scale, fz = (float)d.z * scale;
     const double od = (double)fx * ox + (double)fy * oy + (double)fz * oz;
     const double o2 = (double)ox * ox + (double)oy * oy + (double)oz * oz;
-    const float S = __builtin_sqrtf((float)o2) * 1.0001f + cmax;
+    const float S = bound_sqrtf((float)o2) * 1.0001f + cmax;
     const float Eh = (wide ? BROAD_WIDE_EH : 14.0f) * F32_U * S;
     const float E0 = (wide ? BROAD_WIDE_E0 : 24.0f) * F32_U * S * S;
     r.a = make_float4(-fx, -fy, -fz, (float)od);

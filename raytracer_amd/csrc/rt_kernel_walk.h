@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
         }
 
         // error scale of this ray's float tests: |o| + largest |c| + R (as in broad_setup)
-        const float S = __builtin_sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) * 1.0001f + w.kp.cmax;
+        const float S = bound_sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) * 1.0001f + w.kp.cmax;
         float tU = inf;
         unsigned n = 0, cur_j = 0xffffffffu, cur_m = 0u;
 
@@ -116,10 +116,12 @@ __global__ __launch_bounds__(256) void walk_kernel(const WfParams w, const GridD
                 const float disc = __builtin_fmaf(hb, hb, r2 - oc2);
                 // bound of the float discriminant's error, about 3x the term-by-term count: rounding of o and c to
                 // float and of their difference (S |oc|), of the products and sums (oc2), of d (hb^2 + oc2)
-                const float M = (48.0f * F32_U) * __builtin_fmaf(S, __builtin_sqrtf(oc2), oc2) + (16.0f * F32_U) * __builtin_fmaf(hb, hb, oc2) + 1e-12f;
+                const float M = (48.0f * F32_U) * __builtin_fmaf(S, bound_sqrtf(oc2), oc2) + (16.0f * F32_U) * __builtin_fmaf(hb, hb, oc2) + 1e-12f;
                 if (disc > M) {
-                    const float sq = __builtin_sqrtf(disc);
-                    const float Mt = 2.0f * __builtin_sqrtf(M) + (8.0f * F32_U) * (__builtin_fabsf(hb) + sq + S) + 1e-6f;
+                    // (square roots within a unit in the last place: the root's error term has two units more than the eight
+                    // that the correctly rounded ones were given)
+                    const float sq = bound_sqrtf(disc);
+                    const float Mt = 2.0f * bound_sqrtf(M) * 1.000001f + (10.0f * F32_U) * (__builtin_fabsf(hb) + sq + S) + 1e-6f;
                     const float ta = -hb - sq, tb = sq - hb;
                     const float lim = (float)RT_EPS + Mt;
                     const float th = ta > lim ? ta : (tb > lim ? tb : inf);
