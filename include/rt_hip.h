@@ -120,7 +120,8 @@ enum {
     RT_OPT_MAX_SLOTS = 6,      /* pixels whose path state is kept at once (memory cap)          */
     RT_OPT_FUSE_NARROW = 7,    /* retired (the narrow phase always runs inside shade_kernel); accepted, ignored */
     RT_OPT_OVERLAP = 8,        /* 1..3 sub-pipelines, each with an equal share of the pixels and a stream of its  */
-                               /* own, so that one's kernels fill the tails of the other's (default 2)            */
+                               /* own, so that one's kernels fill the tails of the other's (default 2; left alone, */
+                               /* the library takes 3 for a grid-walk render of 4.7 M pixels or more)              */
     RT_OPT_ACCEL = 9           /* where a ray's candidate solids come from (RT_ACCEL_*); the closest hit and every   */
                                /* output bit are the same whichever is used                                        */
 };

@@ -87,6 +87,7 @@ struct rt_context {
     int chunk_records = 8192;  // LDS window in records (16 bytes each)
     size_t max_slots = (size_t)1 << 25;
     int overlap = 2;           // pipeline: 2 = two half-frame sub-pipelines on two streams (broad of one beside shade of the other)
+    bool overlap_chosen = false;   // set by rt_set_option / RT_OVERLAP: the library then does not pick three parts for a grid-walk render
     uint64_t overlap_min_pixels = 3ull << 20;   // ... for renders of at least this many pixels (RT_OVERLAP_MIN_PIXELS), see render_pipeline
     int last_sub = 1;          // sub-pipelines of the last render
     int broad_mfma = 1;        // 1: the broad phase runs on the matrix cores (broad_mfma_kernel), 0: on the vector ALU (broad_kernel)

@@ -168,7 +168,7 @@ int rt_set_option(rt_handle h, int key, int value) {
             h->max_slots = (size_t)value; return RT_OK;
         case RT_OPT_OVERLAP:
             if (value < 1 || value > RT_MAX_SUB) return fail(h, RT_ERR_ARG, "rt_set_option: overlap must be 1..3");
-            h->overlap = value; return RT_OK;
+            h->overlap = value; h->overlap_chosen = true; return RT_OK;
         case RT_OPT_ACCEL:
             if (value != RT_ACCEL_SCAN && value != RT_ACCEL_WALK && value != RT_ACCEL_AUTO) return fail(h, RT_ERR_ARG, "rt_set_option: accel must be 0 (scan), 1 (grid walk) or 2 (chosen per scene)");
             h->accel = value; return RT_OK;
@@ -621,6 +621,11 @@ static int ensure_pipeline(rt_handle h, rt_context::PipeBufs& b, size_t slots, i
     return RT_OK;
 }
 
+// does the next pipeline render take its candidate solids from the grid walk?
+static bool walk_render(rt_handle h) {
+    return h->grid_ok && (h->accel == RT_ACCEL_WALK || (h->accel == RT_ACCEL_AUTO && h->n_bounded > h->accel_min_bounded));
+}
+
 static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, double* d_rgb, int32_t* d_hit_ids, hipStream_t st) {
     const int rows = rt_rows_for_rank(h->height, tile_rows, rank, world);
     const uint64_t total = (uint64_t)rows * (uint64_t)h->width;
@@ -636,7 +641,12 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     // that one of 8 ranks renders (1.04 M pixels) takes 0.80 ms in one piece and 0.89 ms in two, a 1920 x 1080 frame 0.47
     // against 0.51 ms; from 4 M pixels on two parts win (half a 4K frame 2.50 against 2.54 ms, an eighth of an 8K frame with
     // the grid walk 5.8 against 6.6 ms).
-    const int nsub = (h->overlap >= 2 && !h->timing_detail && total >= h->overlap_min_pixels && total >= (1u << 16)) ? h->overlap : 1;
+    // With the grid walk as candidate source three parts do better than two (8K, 4096 spheres: 39.4 against 39.7 ms; 4K, 16 384
+    // solids, 16 samples: 268 against 277 ms -- a wave walks as long as its longest ray, which leaves more of a launch's
+    // tail to fill); with the scan they are level (8K) or lose (4K: 4.42 against 4.36 ms).  Parts of 1.5 M pixels at least.
+    int parts = h->overlap;
+    if (!h->overlap_chosen && parts == 2 && walk_render(h) && total >= 3 * (h->overlap_min_pixels / 2)) parts = 3;
+    const int nsub = (parts >= 2 && !h->timing_detail && total >= h->overlap_min_pixels && total >= (1u << 16)) ? parts : 1;
     h->last_sub = nsub;
     uint64_t sub_begin[RT_MAX_SUB + 1];
     for (int p = 0; p <= nsub; p++) sub_begin[p] = p == nsub ? total : (total * p / nsub + 63) / 64 * 64;
@@ -670,7 +680,7 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     // frame is the same bit for bit; left to the library the choice follows the measured crossover: the scan up to one LDS
     // window of the binned kernel (32 groups = 1024 bounded solids; 4K room: 5.3 against 5.8 ms), the walk beyond it (1536
     // solids 6.0 against 7.1 ms, 4096: 7.5 against 10.1, 6144: 8.5 against 12.3)
-    const bool use_grid = h->grid_ok && (h->accel == RT_ACCEL_WALK || (h->accel == RT_ACCEL_AUTO && h->n_bounded > h->accel_min_bounded));
+    const bool use_grid = walk_render(h);
     h->accel_used = use_grid ? RT_ACCEL_WALK : RT_ACCEL_SCAN;
     // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
     const bool use_mfma = h->broad_mfma && !use_grid && h->d_frags;

@@ -154,3 +154,21 @@ def test_library_splits_large_renders_only(monkeypatch):
         assert own.timing()["sub_pipelines"] == 1
     finally:
         own.close(); split.close()
+    # left alone, the library takes three parts for a grid-walk render of 4.7 M pixels or more (same frame again)
+    monkeypatch.delenv("RT_OVERLAP_MIN_PIXELS", raising=False)
+    auto, two = api.Renderer(0), api.Renderer(0)
+    try:
+        _, sc = synth.make("c2", width=3072)
+        for r in (auto, two):
+            r.set_option(api.OPT_ACCEL, api.ACCEL_WALK)
+            r.upload(sc)
+        two.set_option(api.OPT_OVERLAP, 2)
+        a, b = auto.render(), two.render()
+        assert auto.timing()["sub_pipelines"] == 3 and two.timing()["sub_pipelines"] == 2
+        assert np.array_equal(a["rgb"].view(np.uint64), b["rgb"].view(np.uint64))
+        auto.set_option(api.OPT_ACCEL, api.ACCEL_SCAN)
+        auto.upload(sc)
+        auto.render()
+        assert auto.timing()["sub_pipelines"] == 2
+    finally:
+        auto.close(); two.close()
