@@ -677,9 +677,10 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     else e = broad_grid<512>(h, &bgrid);
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
     // Where a ray's candidate solids come from.  Both sources hand the exact phase a superset of what it can accept, so the
-    // frame is the same bit for bit; left to the library the choice follows the measured crossover: the scan up to one LDS
-    // window of the binned kernel (32 groups = 1024 bounded solids; 4K room: 5.3 against 5.8 ms), the walk beyond it (1536
-    // solids 6.0 against 7.1 ms, 4096: 7.5 against 10.1, 6144: 8.5 against 12.3)
+    // frame is the same bit for bit; left to the library the choice follows the measured crossover (4K room, ms per frame scan /
+    // walk): 1024 solids 4.33 / 5.28, 1280: 5.47 / 5.57, 1792: 5.95 / 6.02, 2048: 5.36 / 6.17, 2560: 7.15 / 6.58, 3072: 6.82 / 6.82,
+    // 4096: 7.49 / 6.79, 6144: 8.69 / 7.67 -- the scan up to two LDS windows of the binned kernel (2048 bounded solids), the
+    // walk beyond
     const bool use_grid = walk_render(h);
     h->accel_used = use_grid ? RT_ACCEL_WALK : RT_ACCEL_SCAN;
     // the scan on the matrix cores (default) or on the vector ALU; per-launch workgroup size 512 either way
