@@ -29,7 +29,7 @@ struct rt_context {
     float mf_scale = 1.0f;                        //   and the power of two by which its lengths are scaled
     int mf_win_groups = 0, mf_windows = 0;        //   groups per LDS window, windows
     bool mf_cull = true;                          //   camera rays' round: group records first (RT_MFMA_CULL=0: scan every group)
-    bool mf_reordered = false;                    //   the table is in Morton order (else file order, and no culling)
+    bool mf_reordered = false;                    //   the table is in its own order, compact groups (else file order, and no culling)
     bool mf_binned = true;                        //   rounds after the camera rays': the binned scan (RT_MFMA_BINNED=0: plain)
     bool mf_behind = true;                        //   binned scan: groups wholly behind a ray's origin are not listed (RT_MFMA_BEHIND=0: listed)
     // measured on the 4K room with 256 .. 2048 spheres (tools/lattice_probe.py): file order wins up to 256 solids, own order
@@ -512,8 +512,8 @@ std::vector<uint4> mf_build_frags(const std::vector<float>& rec, float s) {
     return fr;
 }
 
-// The scene's table for broad_mfma_kernel.  The records are put in an order of their own -- bounded ones along a Morton
-// curve through their centres, so that 32 consecutive records are neighbours in space, then the unbounded ones; records
+// The scene's table for broad_mfma_kernel.  The records are put in an order of their own -- bounded ones by median cuts
+// (mf_kd_order), so that 32 consecutive records are neighbours in space, then the unbounded ones; records
 // that are never kept (solids of the always-tested table) are left out -- and `perm` leads from a place in that order
 // back to the solid's file index (list entries name places; the exact phase looks the file index up).  Every group of 32
 // gets a bounding sphere of its members' bounding spheres; these "group records", 32 to a fragment like ordinary
@@ -536,6 +536,31 @@ inline unsigned mf_spread10(unsigned v) {          // 10 bits -> every third bit
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
+#ifndef MF_ORDER_MORTON
+#define MF_ORDER_MORTON 0       // 1: the records along a Morton curve through their centres (each axis cut into 1024 steps of its own extent)
+#endif
+// The order of the bounded records: the set is cut in two across the axis along which its centres spread furthest, at a
+// multiple of 32 records nearest the middle, and so on down to groups of 32 -- whatever the solids' arrangement, a group
+// is a compact block, consecutive groups are siblings (an LDS window of 32 groups is a block too), and only the last
+// group can be short.  (A Morton curve does as well for a 16 x 8 x 8 lattice and worse for a 16 x 12 x 8 one, where its
+// power-of-two cuts fall between the lattice's planes unevenly.)  Ties by file index; a group's members in file order.
+inline void mf_kd_order(std::vector<int>& idx, int lo, int hi, const float* rec) {
+    const int n = hi - lo;
+    if (n <= BROAD_GROUP) { std::sort(idx.begin() + lo, idx.begin() + hi); return; }
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = lo; k < hi; k++)
+        for (int a = 0; a < 3; a++) { const float v = rec[4 * (size_t)idx[k] + a]; if (v < blo[a]) blo[a] = v; if (v > bhi[a]) bhi[a] = v; }
+    int ax = 0;
+    for (int a = 1; a < 3; a++) if (bhi[a] - blo[a] > bhi[ax] - blo[ax]) ax = a;
+    const int groups = (n + BROAD_GROUP - 1) / BROAD_GROUP;
+    const int mid = lo + (groups / 2) * BROAD_GROUP;
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int a, int b) {
+        const float va = rec[4 * (size_t)a + ax], vb = rec[4 * (size_t)b + ax];
+        return va < vb || (va == vb && a < b);
+    });
+    mf_kd_order(idx, lo, mid, rec);
+    mf_kd_order(idx, mid, hi, rec);
+}
 MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, bool reorder) {
     MfTable t;
     t.reordered = reorder;
@@ -549,6 +574,7 @@ MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, 
         for (int k = 0; k < 3; k++) { if (r[k] < lo[k]) lo[k] = r[k]; if (r[k] > hi[k]) hi[k] = r[k]; }
     }
     std::vector<std::pair<unsigned, int>> keyed;
+#if MF_ORDER_MORTON
     for (int i : bounded) {
         unsigned q[3];
         for (int k = 0; k < 3; k++) {
@@ -559,6 +585,10 @@ MfTable mf_build_table(const float* rec_file, int n_prims, double cmax_records, 
         keyed.push_back({mf_spread10(q[0]) | (mf_spread10(q[1]) << 1) | (mf_spread10(q[2]) << 2), i});
     }
     std::sort(keyed.begin(), keyed.end());
+#else
+    mf_kd_order(bounded, 0, (int)bounded.size(), rec_file);
+    for (size_t k = 0; k < bounded.size(); k++) keyed.push_back({(unsigned)k, bounded[k]});
+#endif
     const unsigned NONE = 0x7fffffffu;                        // a place that holds no solid
     if (reorder) {
         for (auto& kv : keyed) t.perm.push_back((unsigned)kv.second);

@@ -469,7 +469,7 @@ int rt_upload_scene(rt_handle h, const double* params, int n_prims, const double
     if (alw.empty()) alw.push_back(0.0);
 
     // the matrix-core scan's table; its group records can reach further out than any record, and cmax covers both
-    // Its own (Morton) record order lets the scan ask the groups' bounding spheres first (per tile for the camera rays,
+    // Its own record order (compact groups of 32, mf_kd_order) lets the scan ask the groups' bounding spheres first (per tile for the camera rays,
     // per ray afterwards); it needs groups enough to drop.  Below that the table keeps the file order (consecutive solids
     // of a scene file tend to be neighbours along some line, which packs a ray's hits into few mask words).
     int n_bounded = 0;

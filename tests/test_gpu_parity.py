@@ -197,7 +197,7 @@ def test_baseline_configs_reduced(renderer, cfg, width, kw):
 
 
 def test_group_record_pass_drops_groups_not_hits(renderer, monkeypatch):
-    """With its table in Morton order the matrix-core scan asks the bounding spheres of the 32-record groups first (per
+    """With its table in its own order (compact groups of 32) the matrix-core scan asks the bounding spheres of the 32-record groups first (per
     tile in the camera rays' round, per ray afterwards).  It must compute clearly fewer (32 rays x 32 records) products
     than rays x groups and leave every output bit as it is without that (RT_MFMA_CULL=0: file order, every group scanned)."""
     _, sc = synth.make("c3", width=960)
@@ -260,7 +260,7 @@ def test_binned_scan_variants_do_not_change_bits(renderer, monkeypatch, env):
 
 def test_reordered_table_with_unbounded_records_matches_oracle(monkeypatch):
     """More planes than the always-tested table takes (64): the rest stay records of the scan that every ray keeps, here
-    in a table that is in its own (Morton) order -- forced for these 320 spheres, with the group records asked per tile in
+    in a table that is in its own order -- forced for these 320 spheres, with the group records asked per tile in
     the camera rays' round and the binned scan afterwards."""
     import random
     rng = random.Random(7)
@@ -287,7 +287,7 @@ def test_reordered_table_with_unbounded_records_matches_oracle(monkeypatch):
 
 
 def test_flat_sphere_layer_in_own_table_order_matches_oracle(renderer):
-    """600 spheres in one plane z = const (no extent along one axis for the Morton curve), some of them concentric:
+    """600 spheres in one plane z = const (no extent along one axis for the table's cuts), some of them concentric:
     enough for the scan's table to take its own order; pinned by the oracle."""
     objs = synth._room(2, 0)
     for i in range(600):

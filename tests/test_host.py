@@ -353,7 +353,7 @@ def test_matrix_core_table_order_and_group_spheres():
         d = np.linalg.norm(c[m] - gs[g, :3], axis=1) + r[m]
         assert (d <= gs[g, 3] * (1 + 1e-9)).all()
         spread_sorted.append(gs[g, 3])
-    # file order of random points: every group spans the scene; Morton order: a fraction of it
+    # file order of random points: every group spans the scene; the table's own order: a fraction of it
     _, gs_file = api.mfma_table_order(c, np.where(never | unb, 0.5, r), reorder=False)
     assert np.mean(spread_sorted) < 0.6 * np.mean(gs_file[:, 3])
     perm_f, _ = api.mfma_table_order(c, r, reorder=False)
