@@ -95,7 +95,7 @@ struct rt_context {
     bool no_box = false;       // diagnostic: always-tested planes and faces through the general test only
     int accel = RT_ACCEL_AUTO; // pipeline: candidate lists from the scan of every record (0), from the grid walk (1), or whichever is
                                // faster for the scene (2: the walk above accel_min_bounded bounded solids)
-    int accel_min_bounded = 2 * MFB_GROUPS * BROAD_GROUP;   // RT_ACCEL_MIN_BOUNDED: the walk is chosen when the scene has more bounded solids (two LDS windows of the binned scan)
+    int accel_min_bounded = 3 * MFB_GROUPS * BROAD_GROUP;   // RT_ACCEL_MIN_BOUNDED: the walk is chosen when the scene has more bounded solids (three LDS windows of the binned scan)
                                                         // outside the always-tested table than this (1024: one window of the binned scan)
     int n_bounded = 0;                   // such solids in the uploaded scene
     int accel_used = RT_ACCEL_SCAN;      // what the last render used

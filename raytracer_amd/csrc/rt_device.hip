@@ -678,8 +678,8 @@ static int render_pipeline(rt_handle h, int tile_rows, int rank, int world, doub
     if (e != hipSuccess) return fail(h, RT_ERR_HIP, std::string("broad kernel setup: ") + hipGetErrorString(e));
     // Where a ray's candidate solids come from.  Both sources hand the exact phase a superset of what it can accept, so the
     // frame is the same bit for bit; left to the library the choice follows the measured crossover (4K room, ms per frame scan /
-    // walk): 1024 solids 4.33 / 5.28, 1280: 5.47 / 5.57, 1792: 5.95 / 6.02, 2048: 5.36 / 6.17, 2560: 7.15 / 6.58, 3072: 6.82 / 6.82,
-    // 4096: 7.49 / 6.79, 6144: 8.69 / 7.67 -- the scan up to two LDS windows of the binned kernel (2048 bounded solids), the
+    // walk): 1024 solids 4.33 / 5.28, 1280: 5.18 / 5.57, 1792: 5.51 / 6.02, 2048: 5.31 / 6.17, 2560: 6.36 / 6.58, 3072: 6.43 / 6.82,
+    // 4096: 7.50 / 6.79, 6144: 8.48 / 7.67 -- the scan up to three LDS windows of the binned kernel (3072 bounded solids), the
     // walk beyond
     const bool use_grid = walk_render(h);
     h->accel_used = use_grid ? RT_ACCEL_WALK : RT_ACCEL_SCAN;

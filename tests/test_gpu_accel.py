@@ -111,12 +111,12 @@ def test_walk_full_size_equals_scan(renderer, cfg):
 
 
 def test_library_picks_the_candidate_source_per_scene(monkeypatch):
-    """RT_ACCEL_AUTO (the default of a fresh context): the scan up to 2048 bounded solids, the grid walk beyond;
+    """RT_ACCEL_AUTO (the default of a fresh context): the scan up to 3072 bounded solids, the grid walk beyond;
     rt_timing.accel_used names the one that ran, and the frame is the same bit for bit either way."""
     monkeypatch.delenv("RT_ACCEL", raising=False)
     r = api.Renderer(0)
     try:
-        for lattice, want in (((8, 8, 8), api.ACCEL_SCAN), ((16, 8, 8), api.ACCEL_SCAN), ((16, 16, 8), api.ACCEL_SCAN), ((16, 16, 10), api.ACCEL_WALK)):
+        for lattice, want in (((8, 8, 8), api.ACCEL_SCAN), ((16, 8, 8), api.ACCEL_SCAN), ((16, 16, 12), api.ACCEL_SCAN), ((16, 16, 16), api.ACCEL_WALK)):
             _, sc = synth.make("c3", width=192, lattice=lattice)
             r.upload(sc)
             auto = r.render(want_hits=True)
